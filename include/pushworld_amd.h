@@ -1,0 +1,175 @@
+/*
+ * pushworld_amd.h -- C ABI of the MI355X-native batched PushWorld step engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of google-deepmind/pushworld
+ * that this library accelerates (agent move -> push-chain closure -> collision
+ * test -> goal/reward -> RGB observation).  The reference has no FFI of its own;
+ * each entry point below cites the reference function it replaces (paths are
+ * relative to the reference checkout).  INTEGRATION.md shows the ctypes / C++
+ * stubs a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.
+ *   - every function returns 0 on success or a negative PW_E* code; no C++
+ *     exception crosses the ABI; pw_last_error() returns a thread-local message.
+ *   - "device pointers" are caller-owned HBM buffers (e.g. tensor.data_ptr());
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     are asynchronous on that stream; the engine never allocates per call.
+ *   - calls on one engine must be externally serialised (like the reference
+ *     objects, puzzle.py:310 / pushworld_puzzle.h:178-180, which are not
+ *     re-entrant); different engines are independent.
+ *
+ * State layout in HBM
+ *   pos        int8  [B][NP][2]   (x, y) object origins, agent first, env-major;
+ *                                 NP = pw_engine_npad() in {4, 8, 16, 32}
+ *   puzzle_id  int32 [B]          index into the puzzle set
+ *   steps      int32 [B]          steps since the last reset (gym_env.py:201)
+ *   obs        uint8|float32 [B][Hp*ppc][Wp*ppc][3] with a caller-chosen env
+ *                                 stride (bytes, multiple of 16)
+ */
+#ifndef PUSHWORLD_AMD_H_
+#define PUSHWORLD_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PW_ABI_VERSION 1
+
+/* error codes */
+#define PW_OK 0
+#define PW_EINVAL (-1)     /* bad argument                                   -> ValueError    */
+#define PW_EPARSE (-2)     /* malformed puzzle text (ragged rows, no agent)  -> ValueError    */
+#define PW_EGOAL (-3)      /* goal without movable (puzzle.py:230-232)        -> AssertionError */
+#define PW_ELIMIT (-4)     /* puzzle exceeds engine limits (W,H<=64, N<=32)   -> ValueError    */
+#define PW_EDEVICE (-5)    /* HIP runtime error / no device                   -> RuntimeError  */
+#define PW_ENOMEM (-6)
+
+/* object orderings (SURVEY trap T1) */
+#define PW_ORDER_PYTHON 0  /* puzzle.py:170-257: agent, goals descending, rest in file order */
+#define PW_ORDER_CPP 1     /* pushworld_puzzle.cc:262-321: agent, goals ascending, rest ascending */
+
+/* observation element types */
+#define PW_OBS_U8 0        /* puzzle.py:426-469 image bytes, zero padded                        */
+#define PW_OBS_F32 1       /* env_utils.py:44-91: uint8 -> float32 / 255, zero padded            */
+
+/* pw_step flags */
+#define PW_STEP_AUTORESET 1u /* next-step autoreset: envs whose terminated|truncated flag is
+                                set on entry are reset (reward 0) instead of stepped          */
+
+#define PW_MAX_DIM 64
+#define PW_MAX_OBJECTS 32
+#define PW_POSITION_LIMIT 10000 /* pushworld_puzzle.h:37 */
+
+typedef struct PwPuzzle PwPuzzle;       /* one parsed puzzle (host)                     */
+typedef struct PwPuzzleSet PwPuzzleSet; /* packed bitboard/render tables (host + HBM)   */
+typedef struct PwEngine PwEngine;       /* step/render configuration bound to a set     */
+
+typedef struct PwPuzzleInfo {
+  int32_t width, height;      /* puzzle.py:160-161 (includes the border walls)            */
+  int32_t num_movables;       /* puzzle.py:261                                           */
+  int32_t num_goals;
+  int32_t num_wall_cells;
+  int32_t num_agent_wall_cells; /* raw "aw" cells (without the walls, see trap T2)        */
+  int32_t has_agent_walls;
+  int32_t order;
+} PwPuzzleInfo;
+
+typedef struct PwEngineConfig {
+  int32_t max_steps;        /* <= 0: no truncation (gym_env.py:223)                       */
+  int32_t pixels_per_cell;  /* puzzle.py:26, >= 1 + 2 * border_width                      */
+  int32_t border_width;     /* puzzle.py:22, >= 1                                         */
+  int32_t obs_dtype;        /* PW_OBS_U8 | PW_OBS_F32                                     */
+  int32_t pad_cell_height;  /* observation frame in cells (env_utils.py:44-91);           */
+  int32_t pad_cell_width;   /*   0 = maximum over the puzzle set (gym_env.py:80-82)       */
+} PwEngineConfig;
+
+const char* pw_last_error(void);
+int pw_abi_version(void);
+/* number of visible HIP devices, or PW_EDEVICE */
+int pw_device_count(void);
+
+/* ------------------------------------------------------------------ puzzles (host)
+ * Replaces PushWorldPuzzle.__init__ parsing, puzzle.py:130-257 /
+ * pushworld_puzzle.cc:191-321.  No collision hash-tables are built: the engine
+ * evaluates the reference's collision predicate on row bitboards. */
+int pw_puzzle_parse(const char* text, size_t len, int order, PwPuzzle** out);
+void pw_puzzle_destroy(PwPuzzle* p);
+int pw_puzzle_info(const PwPuzzle* p, PwPuzzleInfo* info);
+/* xy: int32 [num_movables][2] -- puzzle.py:257 initial_state */
+int pw_puzzle_initial_state(const PwPuzzle* p, int32_t* xy);
+/* xy: int32 [num_goals][2] -- puzzle.py:228,256 goal_state */
+int pw_puzzle_goal_state(const PwPuzzle* p, int32_t* xy);
+/* cells of movable `obj` relative to its origin (PushWorldObject.cells, puzzle.py:90).
+ * Returns the cell count (writes at most `cap` pairs) or a negative error. */
+int pw_puzzle_object_cells(const PwPuzzle* p, int obj, int32_t* xy, int cap);
+int pw_puzzle_goal_cells(const PwPuzzle* p, int goal, int32_t* xy, int cap);
+int pw_puzzle_wall_cells(const PwPuzzle* p, int32_t* xy, int cap);       /* puzzle.py:254 */
+int pw_puzzle_agent_wall_cells(const PwPuzzle* p, int32_t* xy, int cap); /* raw "aw" cells */
+/* element id ("a", "m3", ...) of movable `obj`; returns length */
+int pw_puzzle_object_name(const PwPuzzle* p, int obj, char* buf, int cap);
+
+/* --------------------------------------------------------------- puzzle set (HBM)
+ * device >= 0: tables are uploaded to that HIP device.  device < 0: host-only
+ * packing (inspection/tests; engines cannot be created on it). */
+int pw_puzzleset_create(const PwPuzzle* const* puzzles, int n, int device, PwPuzzleSet** out);
+void pw_puzzleset_destroy(PwPuzzleSet* s);
+int pw_puzzleset_size(const PwPuzzleSet* s);
+int pw_puzzleset_max_dims(const PwPuzzleSet* s, int* max_w, int* max_h, int* max_n);
+/* packed table image (host copy), for tests and on-disk caching */
+int pw_puzzleset_blob(const PwPuzzleSet* s, const void** data, size_t* bytes);
+
+/* ---------------------------------------------------------------------- engine */
+int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine** out);
+void pw_engine_destroy(PwEngine* e);
+int pw_engine_npad(const PwEngine* e);                 /* NP of the pos layout           */
+int pw_engine_obs_shape(const PwEngine* e, int* h, int* w, int* c); /* pixels             */
+int64_t pw_engine_obs_bytes(const PwEngine* e);        /* h*w*c*sizeof(elem), unpadded    */
+int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride (16 B aligned) */
+
+/* gym_env.py:150-186 reset(): pos <- initial state of puzzle_id[e], steps <- 0,
+ * terminated/truncated <- 0 (when given), for envs with mask[e] != 0 (mask NULL = all). */
+int pw_reset(PwEngine* e, const int32_t* puzzle_id, const uint8_t* mask, int8_t* pos,
+             int32_t* steps, uint8_t* terminated, uint8_t* truncated, int32_t batch,
+             void* stream);
+
+/* gym_env.py:188-226 step() without the observation:
+ *   pos <- get_next_state(pos, action)                 puzzle.py:348-394
+ *   terminated <- is_goal_state                        puzzle.py:409-411
+ *   reward <- 10.0 | d(count_achieved_goals) - 0.01    gym_env.py:212-221 (float64)
+ *   steps += 1; truncated <- steps >= max_steps        gym_env.py:201,223
+ * reward / dgoals may be NULL.  Actions outside 0..3 leave the env untouched and set
+ * terminated = truncated = 0xFF for that env (the wrappers validate on the host and raise
+ * ValueError like gym_env.py:195-196). */
+int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
+            int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
+            uint8_t* truncated, int32_t batch, uint32_t flags, void* stream);
+
+/* puzzle.py:426-469 render() + env_utils.py:44-91 padding (+ /255 for PW_OBS_F32).
+ * obs: device buffer, env e at obs + e * env_stride_bytes (multiple of 16, base 16 B aligned). */
+int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs,
+              int64_t env_stride_bytes, int32_t batch, void* stream);
+
+/* pw_step followed by pw_render of the new state on the same stream. */
+int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
+                   int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
+                   uint8_t* truncated, void* obs, int64_t env_stride_bytes, int32_t batch,
+                   uint32_t flags, void* stream);
+
+/* Planner successor expansion, best_first_search.h:76-78 calling
+ * PushWorldPuzzle::getNextState (pushworld_puzzle.cc:386-460) and satisfiesGoal (:462-469)
+ * for all 4 actions of F states of ONE puzzle (index `puzzle`, normally PW_ORDER_CPP).
+ *   states int32 [F][N]      Position2D = x * 10000 + y   (pushworld_puzzle.h:32-37)
+ *   succ   int32 [F][4][N]
+ *   moved  uint32 [F][4]     bit k set <=> object k is in moved_object_indices (cc:446-457)
+ *   goal   uint8 [F][4]      satisfiesGoal(successor) */
+int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ,
+               uint32_t* moved, uint8_t* goal, int32_t num_states, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PUSHWORLD_AMD_H_ */

@@ -1,0 +1,436 @@
+// Host side of libpushworld_amd: .pwp parser, bitboard/render table packer and the
+// puzzle / puzzle-set half of the C ABI.
+//
+// Replaces the table construction of the reference constructor
+// (python3/src/pushworld/puzzle.py:130-311, cpp/src/pushworld_puzzle.cc:191-362).  The
+// reference enumerates hash sets of colliding positions (O(cells^2 * overlap), up to
+// 1.5 s per puzzle); here a puzzle is packed into row bitboards in microseconds and the
+// kernels evaluate the same predicate
+//     collides(i, j) <=> shift(mask_i, action) & mask_j != 0  and  mask_i & mask_j == 0
+// directly (puzzle.py:562,592 / pushworld_puzzle.cc:135,168).
+#include "pw_host.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <map>
+#include <set>
+
+static thread_local std::string g_last_error;
+
+void pw_set_error(const std::string& msg) { g_last_error = msg; }
+int pw_fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+namespace {
+
+// Splits on any whitespace like Python's str.split() (puzzle.py:137).  The C++ reference
+// splits on ' ' only (pushworld_puzzle.cc:209-211); the two differ for tabs, which no
+// shipped puzzle contains.
+std::vector<std::string> split_ws(const std::string& line) {
+  std::vector<std::string> out;
+  size_t i = 0, n = line.size();
+  while (i < n) {
+    while (i < n && std::isspace(static_cast<unsigned char>(line[i]))) i++;
+    size_t j = i;
+    while (j < n && !std::isspace(static_cast<unsigned char>(line[j]))) j++;
+    if (j > i) out.push_back(line.substr(i, j - i));
+    i = j;
+  }
+  return out;
+}
+
+std::vector<PwCell> sorted_cells(const std::set<PwCell>& s) {
+  return std::vector<PwCell>(s.begin(), s.end());
+}
+
+uint32_t absent_mask(const std::set<PwCell>& cells, int x, int y) {
+  // puzzle.py:614-638: one border strip per missing 8-neighbour
+  uint32_t m = 0;
+  if (!cells.count({x - 1, y})) m |= PW_NB_L;
+  if (!cells.count({x + 1, y})) m |= PW_NB_R;
+  if (!cells.count({x, y - 1})) m |= PW_NB_U;
+  if (!cells.count({x, y + 1})) m |= PW_NB_D;
+  if (!cells.count({x - 1, y - 1})) m |= PW_NB_UL;
+  if (!cells.count({x + 1, y - 1})) m |= PW_NB_UR;
+  if (!cells.count({x - 1, y + 1})) m |= PW_NB_DL;
+  if (!cells.count({x + 1, y + 1})) m |= PW_NB_DR;
+  return m;
+}
+
+int parse_puzzle(const char* text, size_t len, int order, PwPuzzle* pz) {
+  if (order != PW_ORDER_PYTHON && order != PW_ORDER_CPP)
+    return pw_fail(PW_EINVAL, "order must be PW_ORDER_PYTHON or PW_ORDER_CPP");
+
+  // element id -> absolute cells; `first_seen` keeps the file order of appearance, which
+  // is the dict insertion order the Python reference iterates (puzzle.py:235-237).
+  std::map<std::string, std::set<PwCell>> cells;
+  std::vector<std::string> first_seen;
+
+  int n_cols = -1, n_rows = 0;
+  size_t pos = 0;
+  while (pos < len) {
+    size_t eol = pos;
+    while (eol < len && text[eol] != '\n') eol++;
+    std::string line(text + pos, eol - pos);
+    pos = eol + 1;
+    n_rows++;
+    std::vector<std::string> toks = split_ws(line);
+    if (n_cols < 0) {
+      n_cols = static_cast<int>(toks.size());
+    } else if (static_cast<int>(toks.size()) != n_cols) {
+      return pw_fail(PW_EPARSE, "Row " + std::to_string(n_rows) +
+                                    " does not have the same number of elements as the first row.");
+    }
+    for (int col = 1; col <= static_cast<int>(toks.size()); col++) {
+      const std::string& tok = toks[col - 1];
+      size_t s = 0;
+      while (s <= tok.size()) {
+        size_t e = tok.find('+', s);
+        if (e == std::string::npos) e = tok.size();
+        std::string id = tok.substr(s, e - s);
+        s = e + 1;
+        for (auto& ch : id) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+        if (id.empty() || id == ".") continue;
+        if (!cells.count(id)) first_seen.push_back(id);
+        cells[id].insert({col, n_rows});
+      }
+    }
+  }
+  if (n_cols <= 0 || n_rows <= 0) return pw_fail(PW_EPARSE, "empty puzzle");
+  if (!cells.count("a"))
+    return pw_fail(PW_EPARSE, "Every puzzle must have an agent object, indicated by 'a'.");
+
+  const int W = n_cols + 2, H = n_rows + 2;  // puzzle.py:160-161
+  if (W > PW_MAX_DIM || H > PW_MAX_DIM)
+    return pw_fail(PW_ELIMIT, "puzzle is " + std::to_string(W) + "x" + std::to_string(H) +
+                                  " cells; the engine supports at most 64x64");
+  std::set<PwCell>& wall = cells["w"];
+  for (int x = 0; x < W; x++) {
+    wall.insert({x, 0});
+    wall.insert({x, H - 1});
+  }
+  for (int y = 0; y < H; y++) {
+    wall.insert({0, y});
+    wall.insert({W - 1, y});
+  }
+
+  // goal ids in scan order: descending strings for Python (puzzle.py:178-179), ascending
+  // for C++ (std::map iteration, pushworld_puzzle.cc:274).
+  std::vector<std::string> goal_ids;
+  for (const auto& kv : cells)
+    if (kv.first[0] == 'g') goal_ids.push_back(kv.first);  // ascending
+  if (order == PW_ORDER_PYTHON) std::reverse(goal_ids.begin(), goal_ids.end());
+
+  std::vector<std::string> movables = {"a"};
+  for (const auto& g : goal_ids) {
+    std::string m = "m" + g.substr(1);
+    if (!cells.count(m)) return pw_fail(PW_EGOAL, "Goal has no associated movable object: " + m);
+    movables.push_back(m);
+  }
+  auto listed = [&](const std::string& id) {
+    return std::find(movables.begin(), movables.end(), id) != movables.end();
+  };
+  if (order == PW_ORDER_PYTHON) {
+    for (const auto& id : first_seen)
+      if (id[0] == 'm' && !listed(id)) movables.push_back(id);
+  } else {
+    std::vector<std::string> rest;
+    for (const auto& kv : cells)
+      if (kv.first[0] == 'm' && !listed(kv.first)) rest.push_back(kv.first);  // ascending
+    for (const auto& id : rest) movables.push_back(id);
+  }
+  if (movables.size() > PW_MAX_OBJECTS)
+    return pw_fail(PW_ELIMIT, "puzzle has " + std::to_string(movables.size()) +
+                                  " movables; the engine supports at most 32");
+
+  auto origin_of = [&](const std::set<PwCell>& s) {
+    int mx = 1 << 30, my = 1 << 30;
+    for (const auto& c : s) {
+      mx = std::min(mx, c.first);
+      my = std::min(my, c.second);
+    }
+    return PwCell(mx, my);
+  };
+  auto relative = [&](const std::set<PwCell>& s, PwCell o) {
+    std::set<PwCell> r;
+    for (const auto& c : s) r.insert({c.first - o.first, c.second - o.second});
+    return r;
+  };
+
+  pz->width = W;
+  pz->height = H;
+  pz->order = order;
+  pz->names = movables;
+  for (const auto& id : movables) {
+    PwCell o = origin_of(cells[id]);
+    pz->initial.push_back(o);
+    pz->shapes.push_back(sorted_cells(relative(cells[id], o)));
+  }
+  pz->goal_names = goal_ids;
+  for (const auto& g : goal_ids) {
+    PwCell o = origin_of(cells[g]);
+    pz->goal.push_back(o);
+    pz->goal_shapes.push_back(sorted_cells(relative(cells[g], o)));
+  }
+  pz->walls = sorted_cells(wall);
+  pz->has_agent_walls = cells.count("aw") > 0;
+  if (pz->has_agent_walls) pz->agent_walls = sorted_cells(cells["aw"]);
+  return PW_OK;
+}
+
+template <typename T>
+uint32_t append(std::vector<uint8_t>& blob, const std::vector<T>& v) {
+  while (blob.size() % 8) blob.push_back(0);
+  uint32_t off = static_cast<uint32_t>(blob.size());
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(v.data());
+  blob.insert(blob.end(), p, p + v.size() * sizeof(T));
+  return off;
+}
+
+void pack_puzzle(const PwPuzzle& pz, PwPuzzleHeader* hdr, std::vector<uint8_t>& blob) {
+  const int W = pz.width, H = pz.height;
+  const int N = static_cast<int>(pz.names.size()), G = static_cast<int>(pz.goal.size());
+  while (blob.size() % 8) blob.push_back(0);
+  const uint32_t base = static_cast<uint32_t>(blob.size());
+  std::memset(hdr, 0, sizeof(*hdr));
+  hdr->base = base;
+  hdr->W = static_cast<uint8_t>(W);
+  hdr->H = static_cast<uint8_t>(H);
+  hdr->N = static_cast<uint8_t>(N);
+  hdr->G = static_cast<uint8_t>(G);
+  hdr->has_aw = pz.has_agent_walls ? 1 : 0;
+
+  std::set<PwCell> wall(pz.walls.begin(), pz.walls.end());
+  std::set<PwCell> awall(wall);  // trap T2: the agent-wall layer is AW u W (puzzle.py:273)
+  awall.insert(pz.agent_walls.begin(), pz.agent_walls.end());
+
+  std::vector<uint64_t> wall_rows(H, 0), awall_rows(H, 0);
+  for (const auto& c : wall) wall_rows[c.second] |= 1ull << c.first;
+  for (const auto& c : awall) awall_rows[c.second] |= 1ull << c.first;
+  hdr->off_wall = append(blob, wall_rows) - base;
+  hdr->off_awall = append(blob, awall_rows) - base;
+
+  std::vector<PwObjEntry> objtab(N);
+  std::vector<uint64_t> shape_rows;
+  for (int j = 0; j < N; j++) {
+    int w = 0, h = 0;
+    for (const auto& c : pz.shapes[j]) {
+      w = std::max(w, c.first + 1);
+      h = std::max(h, c.second + 1);
+    }
+    objtab[j].w = static_cast<uint8_t>(w);
+    objtab[j].h = static_cast<uint8_t>(h);
+    objtab[j].row_off = static_cast<uint16_t>(shape_rows.size());
+    std::vector<uint64_t> rows(h, 0);
+    for (const auto& c : pz.shapes[j]) rows[c.second] |= 1ull << c.first;
+    shape_rows.insert(shape_rows.end(), rows.begin(), rows.end());
+  }
+  hdr->off_objtab = append(blob, objtab) - base;
+  hdr->off_shapes = append(blob, shape_rows) - base;
+
+  std::vector<int8_t> init(2 * N), goal(2 * std::max(G, 1), 0);
+  for (int j = 0; j < N; j++) {
+    init[2 * j] = static_cast<int8_t>(pz.initial[j].first);
+    init[2 * j + 1] = static_cast<int8_t>(pz.initial[j].second);
+  }
+  for (int g = 0; g < G; g++) {
+    goal[2 * g] = static_cast<int8_t>(pz.goal[g].first);
+    goal[2 * g + 1] = static_cast<int8_t>(pz.goal[g].second);
+  }
+  hdr->off_init = append(blob, init) - base;
+  hdr->off_goal = append(blob, goal) - base;
+
+  // static render codes: painter's order AW(uW) -> W, goal outlines kept separately in
+  // the top byte (puzzle.py:453-458).
+  std::vector<uint32_t> codes(static_cast<size_t>(W) * H, 0);
+  if (pz.has_agent_walls)
+    for (const auto& c : awall)
+      codes[c.second * W + c.first] = (1u << PW_CODE_KIND_SHIFT) | absent_mask(awall, c.first, c.second);
+  for (const auto& c : wall)
+    codes[c.second * W + c.first] = (2u << PW_CODE_KIND_SHIFT) | absent_mask(wall, c.first, c.second);
+  for (int g = 0; g < G; g++) {
+    std::set<PwCell> gs(pz.goal_shapes[g].begin(), pz.goal_shapes[g].end());
+    for (const auto& c : gs) {
+      int x = pz.goal[g].first + c.first, y = pz.goal[g].second + c.second;
+      codes[y * W + x] |= absent_mask(gs, c.first, c.second) << PW_CODE_GOAL_SHIFT;
+    }
+  }
+  hdr->off_static = append(blob, codes) - base;
+
+  std::vector<uint32_t> mcells;
+  for (int j = 0; j < N; j++) {
+    std::set<PwCell> s(pz.shapes[j].begin(), pz.shapes[j].end());
+    for (const auto& c : s)
+      mcells.push_back(static_cast<uint32_t>(c.first) | (static_cast<uint32_t>(c.second) << 8) |
+                       (absent_mask(s, c.first, c.second) << 16) | (static_cast<uint32_t>(j) << 24));
+  }
+  hdr->n_mcells = static_cast<uint32_t>(mcells.size());
+  if (mcells.empty()) mcells.push_back(0);
+  hdr->off_mcells = append(blob, mcells) - base;
+}
+
+int copy_cells(const std::vector<PwCell>& v, int32_t* xy, int cap) {
+  int n = static_cast<int>(v.size());
+  if (xy)
+    for (int i = 0; i < n && i < cap; i++) {
+      xy[2 * i] = v[i].first;
+      xy[2 * i + 1] = v[i].second;
+    }
+  return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pw_last_error(void) { return g_last_error.c_str(); }
+int pw_abi_version(void) { return PW_ABI_VERSION; }
+
+int pw_device_count(void) {
+  int n = 0;
+  hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess) return pw_fail(PW_EDEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(err));
+  return n;
+}
+
+int pw_puzzle_parse(const char* text, size_t len, int order, PwPuzzle** out) {
+  if (!text || !out) return pw_fail(PW_EINVAL, "null argument");
+  PwPuzzle* pz = new (std::nothrow) PwPuzzle();
+  if (!pz) return pw_fail(PW_ENOMEM, "out of memory");
+  int rc;
+  try {
+    rc = parse_puzzle(text, len, order, pz);
+  } catch (const std::exception& e) {
+    rc = pw_fail(PW_ENOMEM, e.what());
+  }
+  if (rc != PW_OK) {
+    delete pz;
+    return rc;
+  }
+  *out = pz;
+  return PW_OK;
+}
+
+void pw_puzzle_destroy(PwPuzzle* p) { delete p; }
+
+int pw_puzzle_info(const PwPuzzle* p, PwPuzzleInfo* info) {
+  if (!p || !info) return pw_fail(PW_EINVAL, "null argument");
+  info->width = p->width;
+  info->height = p->height;
+  info->num_movables = static_cast<int32_t>(p->names.size());
+  info->num_goals = static_cast<int32_t>(p->goal.size());
+  info->num_wall_cells = static_cast<int32_t>(p->walls.size());
+  info->num_agent_wall_cells = static_cast<int32_t>(p->agent_walls.size());
+  info->has_agent_walls = p->has_agent_walls ? 1 : 0;
+  info->order = p->order;
+  return PW_OK;
+}
+
+int pw_puzzle_initial_state(const PwPuzzle* p, int32_t* xy) {
+  if (!p || !xy) return pw_fail(PW_EINVAL, "null argument");
+  copy_cells(p->initial, xy, static_cast<int>(p->initial.size()));
+  return PW_OK;
+}
+
+int pw_puzzle_goal_state(const PwPuzzle* p, int32_t* xy) {
+  if (!p) return pw_fail(PW_EINVAL, "null argument");
+  copy_cells(p->goal, xy, static_cast<int>(p->goal.size()));
+  return PW_OK;
+}
+
+int pw_puzzle_object_cells(const PwPuzzle* p, int obj, int32_t* xy, int cap) {
+  if (!p || obj < 0 || obj >= static_cast<int>(p->shapes.size())) return pw_fail(PW_EINVAL, "bad object index");
+  return copy_cells(p->shapes[obj], xy, cap);
+}
+
+int pw_puzzle_goal_cells(const PwPuzzle* p, int goal, int32_t* xy, int cap) {
+  if (!p || goal < 0 || goal >= static_cast<int>(p->goal_shapes.size())) return pw_fail(PW_EINVAL, "bad goal index");
+  return copy_cells(p->goal_shapes[goal], xy, cap);
+}
+
+int pw_puzzle_wall_cells(const PwPuzzle* p, int32_t* xy, int cap) {
+  if (!p) return pw_fail(PW_EINVAL, "null argument");
+  return copy_cells(p->walls, xy, cap);
+}
+
+int pw_puzzle_agent_wall_cells(const PwPuzzle* p, int32_t* xy, int cap) {
+  if (!p) return pw_fail(PW_EINVAL, "null argument");
+  return copy_cells(p->agent_walls, xy, cap);
+}
+
+int pw_puzzle_object_name(const PwPuzzle* p, int obj, char* buf, int cap) {
+  if (!p || obj < 0 || obj >= static_cast<int>(p->names.size())) return pw_fail(PW_EINVAL, "bad object index");
+  const std::string& s = p->names[obj];
+  if (buf && cap > 0) {
+    int n = std::min<int>(cap - 1, static_cast<int>(s.size()));
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return static_cast<int>(s.size());
+}
+
+int pw_puzzleset_create(const PwPuzzle* const* puzzles, int n, int device, PwPuzzleSet** out) {
+  if (!puzzles || !out || n <= 0) return pw_fail(PW_EINVAL, "empty puzzle set");
+  PwPuzzleSet* s = new (std::nothrow) PwPuzzleSet();
+  if (!s) return pw_fail(PW_ENOMEM, "out of memory");
+  s->device = device;
+  s->count = n;
+  s->headers.resize(n);
+  for (int i = 0; i < n; i++) {
+    if (!puzzles[i]) {
+      delete s;
+      return pw_fail(PW_EINVAL, "null puzzle in set");
+    }
+    pack_puzzle(*puzzles[i], &s->headers[i], s->blob);
+    s->max_w = std::max(s->max_w, puzzles[i]->width);
+    s->max_h = std::max(s->max_h, puzzles[i]->height);
+    s->max_n = std::max(s->max_n, static_cast<int>(puzzles[i]->names.size()));
+  }
+  while (s->blob.size() % 16) s->blob.push_back(0);
+  if (device >= 0) {
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&s->d_headers), n * sizeof(PwPuzzleHeader));
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&s->d_blob), s->blob.size());
+    if (err == hipSuccess)
+      err = hipMemcpy(s->d_headers, s->headers.data(), n * sizeof(PwPuzzleHeader), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(s->d_blob, s->blob.data(), s->blob.size(), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+      std::string msg = std::string("puzzle set upload failed: ") + hipGetErrorString(err);
+      pw_puzzleset_destroy(s);
+      return pw_fail(PW_EDEVICE, msg);
+    }
+  }
+  *out = s;
+  return PW_OK;
+}
+
+void pw_puzzleset_destroy(PwPuzzleSet* s) {
+  if (!s) return;
+  if (s->d_headers) (void)hipFree(s->d_headers);
+  if (s->d_blob) (void)hipFree(s->d_blob);
+  delete s;
+}
+
+int pw_puzzleset_size(const PwPuzzleSet* s) { return s ? s->count : pw_fail(PW_EINVAL, "null set"); }
+
+int pw_puzzleset_max_dims(const PwPuzzleSet* s, int* max_w, int* max_h, int* max_n) {
+  if (!s) return pw_fail(PW_EINVAL, "null set");
+  if (max_w) *max_w = s->max_w;
+  if (max_h) *max_h = s->max_h;
+  if (max_n) *max_n = s->max_n;
+  return PW_OK;
+}
+
+int pw_puzzleset_blob(const PwPuzzleSet* s, const void** data, size_t* bytes) {
+  if (!s || !data || !bytes) return pw_fail(PW_EINVAL, "null argument");
+  *data = s->blob.data();
+  *bytes = s->blob.size();
+  return PW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs ``/root/reference``); the fixtures it
+writes are committed and are what travels to the GPU box.  Nothing at test
+time reads ``/root/reference``.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Outputs (all inputs -> expected outputs, no reference code):
+
+* ``golden_meta.json``   per puzzle: dimensions, initial/goal state, object
+  cell lists (Python object order), walls, agent walls (raw and as returned by
+  the reference property = AW u W), collision-table sizes and SHA-256 digests,
+  render / observation SHA-256 digests for several (ppc, bw, padding).
+* ``golden_traj.npz``    per puzzle: action sequences and, for each step, the
+  next positions (int16), float64 reward, terminated flag, goal count.
+* ``golden_states.npz``  random in-bounds (possibly overlapping) states and the
+  reference's 4 successors for each (pins the "not already overlapping"
+  clause and the bounds clause of the collision tables).
+* ``golden_images.npz``  a few complete small uint8 frames for debugging.
+
+Puzzle keys are paths relative to the vendored data roots:
+  ``bench:<level>/<name>.pwp``      pushworld_amd/data/puzzles (levels 1-4)
+  ``l0:<zip member>``               pushworld_amd/data/puzzles/level0.zip
+  ``pytest:<name>.pwp``             tests/puzzles/ref_python
+  ``cpptest:<name>.pwp``            tests/puzzles/ref_cpp
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import zipfile
+
+sys.dont_write_bytecode = True
+REF_SRC = "/root/reference/python3/src"
+sys.path.insert(0, REF_SRC)
+
+import numpy as np  # noqa: E402
+from pushworld.puzzle import PushWorldPuzzle  # noqa: E402  (the reference)
+from pushworld.utils.env_utils import render_observation_padded  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+DATA = os.path.join(REPO, "pushworld_amd", "data")
+
+RENDER_CONFIGS = [(20, 2), (3, 1), (8, 2)]  # (pixels_per_cell, border_width)
+PADS = {"own": None, "l1": (51, 42), "std": (54, 47)}  # (max_cell_height, max_cell_width)
+N_RANDOM_STEPS = 400
+N_L0_PER_FAMILY_TRAIN = 56
+N_L0_PER_FAMILY_TEST = 8
+ACTION_CHARS = {"L": 0, "R": 1, "U": 2, "D": 3}
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def digest_point_set(points):
+    arr = np.array(sorted(points), dtype=np.int32).reshape(-1, 2)
+    return sha(arr)
+
+
+def as_int_state(state):
+    return [[int(v) for v in p] for p in state]
+
+
+def collect_puzzles(tmpdir):
+    out = []
+    for lvl in ("level1", "level2", "level3", "level4"):
+        d = os.path.join(DATA, "puzzles", lvl)
+        for name in sorted(os.listdir(d)):
+            if name.endswith(".pwp"):
+                out.append((f"bench:{lvl}/{name}", os.path.join(d, name)))
+    for tag, sub in (("pytest", "ref_python"), ("cpptest", "ref_cpp")):
+        d = os.path.join(REPO, "tests", "puzzles", sub)
+        for name in sorted(os.listdir(d)):
+            if name.endswith(".pwp"):
+                out.append((f"{tag}:{name}", os.path.join(d, name)))
+    z = zipfile.ZipFile(os.path.join(DATA, "puzzles", "level0.zip"))
+    members = [m for m in z.namelist() if m.endswith(".pwp")]
+    fams = sorted({m.split("/")[1] for m in members})
+    for fam in fams:
+        for split, cnt in (("train", N_L0_PER_FAMILY_TRAIN), ("test", N_L0_PER_FAMILY_TEST)):
+            for i in range(cnt):
+                m = f"level0/{fam}/{split}/level_0_{fam}_{split}_{i}.pwp"
+                assert m in members, m
+                p = os.path.join(tmpdir, m.replace("/", "__"))
+                with open(p, "wb") as f:
+                    f.write(z.read(m))
+                out.append((f"l0:{m}", p))
+    return out
+
+
+def load_plan(key):
+    if not key.startswith("bench:"):
+        return None
+    rel = key[len("bench:"):-len(".pwp")]
+    p = os.path.join(DATA, "solutions", rel + ".yaml")
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        for line in f:
+            if line.startswith("plan:"):
+                return [ACTION_CHARS[c] for c in line.split(":", 1)[1].strip()]
+    return None
+
+
+def rollout(puzzle, actions, start=None):
+    """Reference step + the reward arithmetic of gym_env.py:201-221."""
+    state = puzzle.initial_state if start is None else start
+    n = puzzle.num_movables
+    pos = np.zeros((len(actions), n, 2), np.int16)
+    rew = np.zeros((len(actions),), np.float64)
+    term = np.zeros((len(actions),), np.uint8)
+    cnt = np.zeros((len(actions),), np.int8)
+    for t, a in enumerate(actions):
+        prev = state
+        state = puzzle.get_next_state(state, int(a))
+        terminated = puzzle.is_goal_state(state)
+        if terminated:
+            reward = 10.0
+        else:
+            reward = puzzle.count_achieved_goals(state) - puzzle.count_achieved_goals(prev) - 0.01
+        pos[t] = np.array(as_int_state(state), np.int16).reshape(n, 2)
+        rew[t] = reward
+        term[t] = terminated
+        cnt[t] = puzzle.count_achieved_goals(state)
+    return pos, rew, term, cnt, state
+
+
+def main():
+    meta = {}
+    traj = {}
+    states = {}
+    images = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        puzzles = collect_puzzles(tmp)
+        for idx, (key, path) in enumerate(puzzles):
+            pz = PushWorldPuzzle(path)
+            n = pz.num_movables
+            W, H = pz.dimensions
+            m = {
+                "width": W,
+                "height": H,
+                "num_movables": n,
+                "initial_state": as_int_state(pz.initial_state),
+                "goal_state": as_int_state(pz.goal_state),
+                "object_cells": [sorted([int(x), int(y)] for x, y in o.cells) for o in pz.movable_objects],
+                "goal_cells": [sorted([int(x), int(y)] for x, y in g.cells) for g in pz._goals],
+                "object_fill": [list(o.fill_color) for o in pz.movable_objects],
+                "walls_sha": digest_point_set(pz.wall_positions),
+                "n_walls": len(pz.wall_positions),
+                "agent_walls_prop_sha": digest_point_set(pz.agent_wall_positions),
+                "n_agent_walls_prop": len(pz.agent_wall_positions),
+                "has_agent_walls": pz._agent_walls is not None,
+            }
+            # collision tables: sizes + digest (puzzle.py:262-308)
+            ssz = np.zeros((4, n), np.int32)
+            dsz = np.zeros((4, n, n), np.int32)
+            h = hashlib.sha256()
+            for a in range(4):
+                for i in range(n):
+                    s = pz._agent_collision_map[a] if i == 0 else pz._wall_collision_map[a][i]
+                    ssz[a, i] = len(s)
+                    h.update(np.array(sorted(s), np.int32).tobytes())
+                    for j in range(n):
+                        d = pz._movable_collision_map[a][i][j]
+                        dsz[a, i, j] = len(d)
+                        h.update(np.array(sorted(d), np.int32).tobytes())
+            m["static_sizes"] = ssz.tolist()
+            m["dynamic_sizes"] = dsz.tolist()
+            m["tables_sha"] = h.hexdigest()
+
+            # trajectories
+            plan = load_plan(key)
+            rng = np.random.default_rng(1000 + idx)
+            seqs = {}
+            if plan is not None:
+                assert pz.is_valid_plan(plan), key
+                seqs["plan"] = (np.array(plan, np.uint8), None)
+                half = len(plan) // 2
+                _, _, _, _, mid_state = rollout(pz, plan[:half])
+                seqs["mid"] = (rng.integers(0, 4, size=200).astype(np.uint8), mid_state)
+            nrand = N_RANDOM_STEPS if not key.startswith("l0:") else 200
+            seqs["rand"] = (rng.integers(0, 4, size=nrand).astype(np.uint8), None)
+            render_states = []
+            for name, (acts, start) in seqs.items():
+                pos, rew, term, cnt, _ = rollout(pz, acts, start)
+                traj[f"{key}|{name}|actions"] = acts
+                traj[f"{key}|{name}|pos"] = pos
+                traj[f"{key}|{name}|reward"] = rew
+                traj[f"{key}|{name}|terminated"] = term
+                traj[f"{key}|{name}|goals"] = cnt
+                if start is not None:
+                    traj[f"{key}|{name}|start"] = np.array(as_int_state(start), np.int16)
+                if name in ("plan", "rand") and (name == "plan" or "plan" not in seqs):
+                    T = len(acts)
+                    for t in sorted({0, T // 2, T - 1}):
+                        render_states.append((name, t, tuple(map(tuple, pos[t].tolist()))))
+            render_states.insert(0, ("init", -1, tuple(map(tuple, as_int_state(pz.initial_state)))))
+
+            # render digests
+            rd = []
+            do_render = not key.startswith("l0:") or idx % 8 == 0
+            if do_render:
+                for (seq, t, st) in render_states:
+                    for (ppc, bw) in RENDER_CONFIGS:
+                        img = pz.render(st, border_width=bw, pixels_per_cell=ppc)
+                        ent = {"seq": seq, "t": t, "state": [list(p) for p in st], "ppc": ppc, "bw": bw,
+                               "u8": sha(img)}
+                        for pname, pad in PADS.items():
+                            mh, mw = (H, W) if pad is None else pad
+                            if mh < H or mw < W:
+                                continue
+                            # float32 at ppc 20 padded to 54x47 is 12 MB per frame; digest only
+                            obs = render_observation_padded(pz, st, mh, mw, ppc, bw)
+                            assert obs.dtype == np.float32
+                            ent[f"f32_{pname}"] = sha(obs)
+                        rd.append(ent)
+            m["renders"] = rd
+            meta[key] = m
+
+            # random in-bounds states (may overlap): 4 successors each
+            if not key.startswith("l0:") or idx % 4 == 0:
+                sizes = []
+                for o in pz.movable_objects:
+                    xs = [c[0] for c in o.cells]
+                    ys = [c[1] for c in o.cells]
+                    sizes.append((max(xs) + 1, max(ys) + 1))
+                S = 24
+                st_in = np.zeros((S, n, 2), np.int16)
+                st_out = np.zeros((S, 4, n, 2), np.int16)
+                for s in range(S):
+                    st = []
+                    for (w, hh) in sizes:
+                        st.append((int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - hh + 1))))
+                    st_in[s] = np.array(st, np.int16)
+                    for a in range(4):
+                        nxt = pz.get_next_state(tuple(st), a)
+                        st_out[s, a] = np.array(as_int_state(nxt), np.int16)
+                states[f"{key}|in"] = st_in
+                states[f"{key}|out"] = st_out
+
+            if key in ("pytest:trivial.pwp", "pytest:trivial_tool.pwp", "pytest:file_parsing.pwp",
+                       "bench:level1/2 Obstacle.pwp"):
+                for (ppc, bw) in RENDER_CONFIGS:
+                    images[f"{key}|init|{ppc}|{bw}"] = pz.render(pz.initial_state, bw, ppc)
+            if idx % 50 == 0:
+                print(f"[{idx}/{len(puzzles)}] {key}", flush=True)
+
+    # the reference's own render hash test (test_puzzle.py:249-271), as data
+    pz = PushWorldPuzzle(os.path.join(REPO, "tests", "puzzles", "ref_python", "trivial.pwp"))
+    frames = pz.render_plan([1, 3, 1, 2])
+    images["pytest:trivial.pwp|render_plan_RDRU"] = np.stack(frames)
+    meta["_reference_test_rendering_hashes"] = [
+        8141256401900123811, 1770142108181252064, 4744825492003518882,
+        -7463149466192975143, -8235536721686713717,
+    ]
+    assert [hash(tuple(f.flat)) for f in frames] == meta["_reference_test_rendering_hashes"]
+
+    with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"), sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "golden_traj.npz"), **traj)
+    np.savez_compressed(os.path.join(HERE, "golden_states.npz"), **states)
+    np.savez_compressed(os.path.join(HERE, "golden_images.npz"), **images)
+    print("puzzles:", len(meta) - 1)
+
+
+if __name__ == "__main__":
+    main()
