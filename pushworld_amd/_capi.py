@@ -1,0 +1,292 @@
+"""ctypes binding of ``libpushworld_amd.so`` (C ABI declared in ``include/pushworld_amd.h``).
+
+The library is the product: there is no Python or CPU fallback.  If it has not been
+built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``python -m pushworld_amd.build``) importing this module raises ``ImportError``, and any
+device operation without a visible MI355X raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+# torch first: it loads its bundled HIP runtime (SONAME libamdhip64.so.7); loading our
+# library afterwards binds to that same runtime, so tensor.data_ptr() values and
+# torch.cuda streams are valid inside the kernels' process-wide HIP context.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpushworld_amd.so")
+
+PW_OK = 0
+PW_EINVAL, PW_EPARSE, PW_EGOAL, PW_ELIMIT, PW_EDEVICE, PW_ENOMEM = -1, -2, -3, -4, -5, -6
+ORDER_PYTHON, ORDER_CPP = 0, 1
+OBS_U8, OBS_F32 = 0, 1
+STEP_AUTORESET = 1
+
+
+class PwPuzzleInfo(ctypes.Structure):
+    _fields_ = [
+        ("width", c_int32),
+        ("height", c_int32),
+        ("num_movables", c_int32),
+        ("num_goals", c_int32),
+        ("num_wall_cells", c_int32),
+        ("num_agent_wall_cells", c_int32),
+        ("has_agent_walls", c_int32),
+        ("order", c_int32),
+    ]
+
+
+class PwEngineConfig(ctypes.Structure):
+    _fields_ = [
+        ("max_steps", c_int32),
+        ("pixels_per_cell", c_int32),
+        ("border_width", c_int32),
+        ("obs_dtype", c_int32),
+        ("pad_cell_height", c_int32),
+        ("pad_cell_width", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); also the list checked by tests/test_capi_symbols.py
+SIGNATURES = {
+    "pw_last_error": (c_char_p, []),
+    "pw_abi_version": (c_int, []),
+    "pw_device_count": (c_int, []),
+    "pw_puzzle_parse": (c_int, [c_char_p, c_size_t, c_int, POINTER(c_void_p)]),
+    "pw_puzzle_destroy": (None, [c_void_p]),
+    "pw_puzzle_info": (c_int, [c_void_p, POINTER(PwPuzzleInfo)]),
+    "pw_puzzle_initial_state": (c_int, [c_void_p, POINTER(c_int32)]),
+    "pw_puzzle_goal_state": (c_int, [c_void_p, POINTER(c_int32)]),
+    "pw_puzzle_object_cells": (c_int, [c_void_p, c_int, POINTER(c_int32), c_int]),
+    "pw_puzzle_goal_cells": (c_int, [c_void_p, c_int, POINTER(c_int32), c_int]),
+    "pw_puzzle_wall_cells": (c_int, [c_void_p, POINTER(c_int32), c_int]),
+    "pw_puzzle_agent_wall_cells": (c_int, [c_void_p, POINTER(c_int32), c_int]),
+    "pw_puzzle_object_name": (c_int, [c_void_p, c_int, c_char_p, c_int]),
+    "pw_puzzleset_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_void_p)]),
+    "pw_puzzleset_destroy": (None, [c_void_p]),
+    "pw_puzzleset_size": (c_int, [c_void_p]),
+    "pw_puzzleset_max_dims": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "pw_puzzleset_blob": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
+    "pw_engine_create": (c_int, [c_void_p, POINTER(PwEngineConfig), POINTER(c_void_p)]),
+    "pw_engine_destroy": (None, [c_void_p]),
+    "pw_engine_npad": (c_int, [c_void_p]),
+    "pw_engine_obs_shape": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "pw_engine_obs_bytes": (c_int64, [c_void_p]),
+    "pw_engine_obs_stride": (c_int64, [c_void_p]),
+    "pw_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "pw_step": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+         c_uint32, c_void_p],
+    ),
+    "pw_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "pw_step_render": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_int64, c_int32, c_uint32, c_void_p],
+    ),
+    "pw_expand4": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP library first "
+            "(python -m pushworld_amd.build).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pw_abi_version() != 1:
+        raise ImportError("libpushworld_amd.so ABI version mismatch; rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    msg = lib.pw_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int) -> int:
+    """Maps error codes to the exception types of the reference."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc in (PW_EINVAL, PW_EPARSE, PW_ELIMIT):
+        raise ValueError(msg)
+    if rc == PW_EGOAL:
+        raise AssertionError(msg)
+    if rc == PW_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count() -> int:
+    n = lib.pw_device_count()
+    return n if n > 0 else 0
+
+
+def _cells(fn, handle, *idx):
+    n = check(fn(handle, *idx, None, 0))
+    buf = (c_int32 * (2 * max(n, 1)))()
+    check(fn(handle, *idx, buf, n))
+    return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+
+class ParsedPuzzle:
+    """Owner of a ``PwPuzzle*`` (host-side parse products)."""
+
+    def __init__(self, text: str, order: int = ORDER_PYTHON):
+        data = text.encode("utf-8")
+        h = c_void_p()
+        check(lib.pw_puzzle_parse(data, len(data), order, ctypes.byref(h)))
+        self.handle = h
+        info = PwPuzzleInfo()
+        check(lib.pw_puzzle_info(h, ctypes.byref(info)))
+        self.width, self.height = info.width, info.height
+        self.num_movables, self.num_goals = info.num_movables, info.num_goals
+        self.has_agent_walls = bool(info.has_agent_walls)
+        self.order = info.order
+        n, g = self.num_movables, self.num_goals
+        buf = (c_int32 * (2 * n))()
+        check(lib.pw_puzzle_initial_state(h, buf))
+        self.initial_state = tuple((buf[2 * i], buf[2 * i + 1]) for i in range(n))
+        gbuf = (c_int32 * (2 * max(g, 1)))()
+        check(lib.pw_puzzle_goal_state(h, gbuf))
+        self.goal_state = tuple((gbuf[2 * i], gbuf[2 * i + 1]) for i in range(g))
+        self.object_cells = [_cells(lib.pw_puzzle_object_cells, h, j) for j in range(n)]
+        self.goal_cells = [_cells(lib.pw_puzzle_goal_cells, h, k) for k in range(g)]
+        self.wall_cells = _cells(lib.pw_puzzle_wall_cells, h)
+        self.agent_wall_cells = _cells(lib.pw_puzzle_agent_wall_cells, h)
+        names = []
+        for j in range(n):
+            nb = ctypes.create_string_buffer(64)
+            check(lib.pw_puzzle_object_name(h, j, nb, 64))
+            names.append(nb.value.decode())
+        self.names = names
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and lib is not None:
+            lib.pw_puzzle_destroy(h)
+            self.handle = None
+
+
+class PuzzleSet:
+    """Owner of a ``PwPuzzleSet*``: packed tables, uploaded to ``device`` (>= 0)."""
+
+    def __init__(self, puzzles, device: int):
+        self.puzzles = list(puzzles)
+        arr = (c_void_p * len(self.puzzles))(*[p.handle for p in self.puzzles])
+        h = c_void_p()
+        check(lib.pw_puzzleset_create(arr, len(self.puzzles), device, ctypes.byref(h)))
+        self.handle = h
+        self.device = device
+        w, hh, n = c_int(), c_int(), c_int()
+        check(lib.pw_puzzleset_max_dims(h, ctypes.byref(w), ctypes.byref(hh), ctypes.byref(n)))
+        self.max_width, self.max_height, self.max_movables = w.value, hh.value, n.value
+
+    def __len__(self):
+        return len(self.puzzles)
+
+    def blob(self) -> bytes:
+        p, n = c_void_p(), c_size_t()
+        check(lib.pw_puzzleset_blob(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p.value, n.value)
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and lib is not None:
+            lib.pw_puzzleset_destroy(h)
+            self.handle = None
+
+
+def _ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Owner of a ``PwEngine*``.  Methods take torch tensors resident on the set's device and
+    enqueue kernels on ``torch.cuda.current_stream()``."""
+
+    def __init__(self, pset: PuzzleSet, max_steps=None, pixels_per_cell=20, border_width=2,
+                 obs_dtype=OBS_F32, pad_cell_height=0, pad_cell_width=0):
+        cfg = PwEngineConfig(
+            int(max_steps) if max_steps is not None else 0,
+            int(pixels_per_cell), int(border_width), int(obs_dtype),
+            int(pad_cell_height), int(pad_cell_width),
+        )
+        h = c_void_p()
+        check(lib.pw_engine_create(pset.handle, ctypes.byref(cfg), ctypes.byref(h)))
+        self.handle = h
+        self.pset = pset  # keep the tables alive
+        self.device = torch.device("cuda", pset.device)
+        self.np = lib.pw_engine_npad(h)
+        oh, ow, oc = c_int(), c_int(), c_int()
+        check(lib.pw_engine_obs_shape(h, ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(oc)))
+        self.obs_shape = (oh.value, ow.value, oc.value)
+        self.obs_bytes = lib.pw_engine_obs_bytes(h)
+        self.obs_stride = lib.pw_engine_obs_stride(h)
+        self.obs_dtype = torch.uint8 if obs_dtype == OBS_U8 else torch.float32
+
+    def _stream(self):
+        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # state buffers -------------------------------------------------------------------
+    def alloc_state(self, batch: int):
+        d = self.device
+        return {
+            "pos": torch.zeros((batch, self.np, 2), dtype=torch.int8, device=d),
+            "steps": torch.zeros((batch,), dtype=torch.int32, device=d),
+            "reward": torch.zeros((batch,), dtype=torch.float64, device=d),
+            "dgoals": torch.zeros((batch,), dtype=torch.int8, device=d),
+            "terminated": torch.zeros((batch,), dtype=torch.uint8, device=d),
+            "truncated": torch.zeros((batch,), dtype=torch.uint8, device=d),
+        }
+
+    def alloc_obs(self, batch: int):
+        """Returns (storage, view): ``view`` has shape (B, H, W, 3) over rows of
+        ``obs_stride`` bytes (16-byte aligned environments)."""
+        esz = 1 if self.obs_dtype == torch.uint8 else 4
+        storage = torch.zeros((batch, self.obs_stride // esz), dtype=self.obs_dtype, device=self.device)
+        h, w, c = self.obs_shape
+        view = storage.as_strided((batch, h, w, c), (self.obs_stride // esz, w * c, c, 1))
+        return storage, view
+
+    # kernels ---------------------------------------------------------------------------
+    def reset(self, puzzle_id, pos, steps, terminated=None, truncated=None, mask=None):
+        check(lib.pw_reset(self.handle, _ptr(puzzle_id), _ptr(mask), _ptr(pos), _ptr(steps), _ptr(terminated),
+                           _ptr(truncated), pos.shape[0], self._stream()))
+
+    def step(self, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, flags=0):
+        check(lib.pw_step(self.handle, _ptr(puzzle_id), _ptr(actions), _ptr(pos), _ptr(steps), _ptr(reward),
+                          _ptr(dgoals), _ptr(terminated), _ptr(truncated), pos.shape[0], flags, self._stream()))
+
+    def render(self, puzzle_id, pos, obs_storage):
+        check(lib.pw_render(self.handle, _ptr(puzzle_id), _ptr(pos), _ptr(obs_storage), self.obs_stride,
+                            pos.shape[0], self._stream()))
+
+    def step_render(self, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, obs_storage,
+                    flags=0):
+        check(lib.pw_step_render(self.handle, _ptr(puzzle_id), _ptr(actions), _ptr(pos), _ptr(steps),
+                                 _ptr(reward), _ptr(dgoals), _ptr(terminated), _ptr(truncated),
+                                 _ptr(obs_storage), self.obs_stride, pos.shape[0], flags, self._stream()))
+
+    def expand4(self, puzzle_index, states, succ, moved, goal):
+        check(lib.pw_expand4(self.handle, int(puzzle_index), _ptr(states), _ptr(succ), _ptr(moved), _ptr(goal),
+                             states.shape[0], self._stream()))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and lib is not None:
+            lib.pw_engine_destroy(h)
+            self.handle = None

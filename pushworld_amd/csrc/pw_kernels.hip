@@ -1,0 +1,854 @@
+// gfx950 (CDNA4 / MI355X) kernels of the batched PushWorld step engine and the engine half
+// of the C ABI.  Written for 64-lane wavefronts; no other target is supported.
+//
+// Dynamics (reference: python3/src/pushworld/puzzle.py:348-394 get_next_state,
+// cpp/src/pushworld_puzzle.cc:386-460 getNextState):
+//   one WAVEFRONT per environment, lane r = grid row r (H <= 64).  Every object is a row
+//   bitboard spread over the wave (one uint64 per lane); "object i pushes object j" is
+//       ballot((shift(row_i, action) & row_j) != 0) != 0  &&  ballot((row_i & row_j) != 0) == 0
+//   which is exactly membership of (pos_i - pos_j) in the reference's dynamic collision set
+//   (puzzle.py:567-593), and likewise for walls (puzzle.py:522-564).  The push set is a
+//   uint32 bit mask grown to a fixed point with wave ballots.
+//
+// Observation (reference: puzzle.py:426-469 render, :596-638 _draw_object,
+// utils/env_utils.py:44-91 render_observation_padded):
+//   one WORKGROUP per environment.  The painter's algorithm is evaluated per cell into an
+//   LDS occupancy/code grid (static layers from the packed puzzle, movables composed with
+//   LDS atomicMax in painter order), expanded to 3x3 zone colours per cell, and streamed to
+//   HBM as coalesced 16-byte stores.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <new>
+#include <string>
+
+#include "pw_host.h"
+
+#define PW_WAVE 64
+
+struct PwEngine {
+  const PwPuzzleSet* set;
+  PwEngineConfig cfg;
+  int np;            // padded object count of the pos layout
+  int pad_h, pad_w;  // observation frame in cells
+  int obs_h, obs_w;  // pixels
+  int64_t obs_bytes;
+  size_t render_lds;
+  uint32_t pal_rgb[16];
+  float pal_f32[16][4];
+};
+
+// ------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
+// Row bitboard of the object displaced by one action.  LEFT/RIGHT are in-lane shifts,
+// UP/DOWN move rows between neighbouring lanes.  Bits leaving the 64x64 frame are dropped,
+// which reproduces the bounds clause of the static tables (puzzle.py:557-561).
+__device__ __forceinline__ uint64_t shift_rows(uint64_t r, int act, int lane) {
+  if (act == 0) return r >> 1;  // LEFT  (-1, 0)
+  if (act == 1) return r << 1;  // RIGHT (+1, 0)
+  if (act == 2) {               // UP    (0, -1): new row y holds old row y + 1
+    uint64_t v = __shfl_down(r, 1, PW_WAVE);
+    return lane == PW_WAVE - 1 ? 0ull : v;
+  }
+  uint64_t v = __shfl_up(r, 1, PW_WAVE);  // DOWN (0, +1)
+  return lane == 0 ? 0ull : v;
+}
+
+struct PuzzleView {
+  const uint64_t* wall;
+  const uint64_t* awall;
+  const PwObjEntry* objtab;
+  const uint64_t* shapes;
+  const int8_t* init;
+  const int8_t* goal;
+  const uint32_t* stat;
+  const uint32_t* mcells;
+  int W, H, N, G, n_mcells;
+};
+
+__device__ __forceinline__ PuzzleView view_of(const PwPuzzleHeader* hdrs, const uint8_t* blob, int pid) {
+  const PwPuzzleHeader& h = hdrs[pid];
+  const uint8_t* b = blob + h.base;
+  PuzzleView v;
+  v.wall = reinterpret_cast<const uint64_t*>(b + h.off_wall);
+  v.awall = reinterpret_cast<const uint64_t*>(b + h.off_awall);
+  v.objtab = reinterpret_cast<const PwObjEntry*>(b + h.off_objtab);
+  v.shapes = reinterpret_cast<const uint64_t*>(b + h.off_shapes);
+  v.init = reinterpret_cast<const int8_t*>(b + h.off_init);
+  v.goal = reinterpret_cast<const int8_t*>(b + h.off_goal);
+  v.stat = reinterpret_cast<const uint32_t*>(b + h.off_static);
+  v.mcells = reinterpret_cast<const uint32_t*>(b + h.off_mcells);
+  v.W = h.W;
+  v.H = h.H;
+  v.N = h.N;
+  v.G = h.G;
+  v.n_mcells = static_cast<int>(h.n_mcells);
+  return v;
+}
+
+// lane r's row of object j placed at (x, y)
+__device__ __forceinline__ uint64_t object_row(const PuzzleView& pv, int j, int x, int y, int lane) {
+  const PwObjEntry e = pv.objtab[j];
+  const int rr = lane - y;
+  uint64_t r = 0;
+  if (static_cast<unsigned>(rr) < static_cast<unsigned>(e.h)) r = pv.shapes[e.row_off + rr];
+  return (static_cast<unsigned>(x) < 64u) ? (r << x) : 0ull;
+}
+
+// Exact pairwise closure for states in which objects already overlap each other or a wall
+// (never produced by legal play; pins the "not already overlapping" clause,
+// puzzle.py:562,592).  Rows are re-read with dynamic indices to keep the code small.
+__device__ __noinline__ uint32_t closure_pairwise(const PuzzleView& pv, int xy_packed, int act, int lane,
+                                                  uint64_t wall) {
+  uint32_t pushed = 1u, frontier = 1u;
+  while (frontier) {
+    const int i = __ffs(frontier) - 1;
+    frontier &= ~(1u << i);
+    const int pi = __builtin_amdgcn_readlane(xy_packed, i);
+    const uint64_t ri = object_row(pv, i, static_cast<int8_t>(pi & 0xff), static_cast<int8_t>((pi >> 8) & 0xff), lane);
+    const uint64_t si = shift_rows(ri, act, lane);
+    for (int j = 1; j < pv.N; j++) {
+      if ((pushed >> j) & 1u) continue;
+      const int pj = __builtin_amdgcn_readlane(xy_packed, j);
+      const uint64_t rj = object_row(pv, j, static_cast<int8_t>(pj & 0xff), static_cast<int8_t>((pj >> 8) & 0xff), lane);
+      if (wave_any((si & rj) != 0) && !wave_any((ri & rj) != 0)) {
+        const uint64_t sj = shift_rows(rj, act, lane);
+        if (wave_any((sj & wall) != 0) && !wave_any((rj & wall) != 0)) return 0u;  // transitive stopping
+        pushed |= 1u << j;
+        frontier |= 1u << j;
+      }
+    }
+  }
+  return pushed;
+}
+
+// Push-set fixed point for one environment held by one wavefront.
+//   row[j]     lane r = row r of object j at its current position (0 for j >= N)
+//   xy_packed  lane j = (x | y << 8) of object j (for the slow path)
+// Returns the bit mask of objects that move (bit 0 = agent), 0 when nothing moves.
+template <int NP>
+__device__ __forceinline__ uint32_t push_closure(const PuzzleView& pv, const uint64_t (&row)[NP], uint64_t wall,
+                                                 uint64_t awall, int xy_packed, int act, int lane) {
+  // agent vs walls + agent walls (puzzle.py:353; static table of the agent, :272-281)
+  const uint64_t s0 = shift_rows(row[0], act, lane);
+  if (wave_any((s0 & awall) != 0) && !wave_any((row[0] & awall) != 0)) return 0u;
+
+  // Is the state free of overlaps (movable/movable and non-agent movable/wall)?  Always true
+  // for states reached by legal play; then the pairwise rule collapses to tests against the
+  // union of the displaced push set.
+  uint64_t acc = row[0], overlap = 0, others = 0;
+#pragma unroll
+  for (int j = 1; j < NP; j++) {
+    overlap |= acc & row[j];
+    acc |= row[j];
+    others |= row[j];
+  }
+  overlap |= others & wall;
+  if (wave_any(overlap != 0)) return closure_pairwise(pv, xy_packed, act, lane, wall);
+
+  if (!wave_any((s0 & others) != 0)) return 1u;  // ~79 % of steps: the agent moves alone
+
+  uint32_t pushed = 1u;
+  uint64_t front = s0;  // displaced rows of the objects added in the previous sweep
+  for (;;) {
+    uint32_t fresh = 0u;
+    uint64_t add = 0;
+#pragma unroll
+    for (int j = 1; j < NP; j++) {
+      if (j < pv.N && !((pushed >> j) & 1u) && wave_any((front & row[j]) != 0)) {
+        fresh |= 1u << j;
+        add |= row[j];
+      }
+    }
+    if (!fresh) break;
+    pushed |= fresh;
+    front = shift_rows(add, act, lane);
+    if (wave_any((front & wall) != 0)) return 0u;  // a pushed object hits a wall: nothing moves
+  }
+  return pushed;
+}
+
+// ------------------------------------------------------------------------------------
+// K0 reset  (gym_env.py:150-186)
+// ------------------------------------------------------------------------------------
+struct ResetArgs {
+  const PwPuzzleHeader* hdrs;
+  const uint8_t* blob;
+  const int32_t* puzzle_id;
+  const uint8_t* mask;
+  int8_t* pos;
+  int32_t* steps;
+  uint8_t* term;
+  uint8_t* trunc;
+  int32_t batch;
+  int32_t np;
+};
+
+__global__ __launch_bounds__(256) void pw_reset_kernel(ResetArgs a) {
+  // one thread per (env, object slot): coalesced int16 stores of the position rows
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int env = static_cast<int>(t / a.np);
+  const int j = static_cast<int>(t - static_cast<int64_t>(env) * a.np);
+  if (env >= a.batch) return;
+  if (a.mask && !a.mask[env]) return;
+  const PwPuzzleHeader& h = a.hdrs[a.puzzle_id[env]];
+  int16_t v = 0;
+  if (j < h.N) v = reinterpret_cast<const int16_t*>(a.blob + h.base + h.off_init)[j];
+  reinterpret_cast<int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + j] = v;
+  if (j == 0) {
+    a.steps[env] = 0;
+    if (a.term) a.term[env] = 0;
+    if (a.trunc) a.trunc[env] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K1 step  (gym_env.py:188-226 minus the observation)
+// ------------------------------------------------------------------------------------
+struct StepArgs {
+  const PwPuzzleHeader* hdrs;
+  const uint8_t* blob;
+  const int32_t* puzzle_id;
+  const uint8_t* actions;
+  int8_t* pos;
+  int32_t* steps;
+  double* reward;
+  int8_t* dgoals;
+  uint8_t* term;
+  uint8_t* trunc;
+  int32_t batch;
+  int32_t max_steps;
+  uint32_t flags;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
+  const int lane = threadIdx.x & (PW_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int env = blockIdx.x * (256 / PW_WAVE) + wave;
+  if (env >= a.batch) return;
+
+  const int pid = __builtin_amdgcn_readfirstlane(a.puzzle_id[env]);
+  const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
+  const int act = __builtin_amdgcn_readfirstlane(static_cast<int>(a.actions[env]));
+  int16_t* prow = reinterpret_cast<int16_t*>(a.pos) + static_cast<int64_t>(env) * NP;
+
+  if ((a.flags & PW_STEP_AUTORESET) && (a.term[env] | a.trunc[env])) {
+    // next-step autoreset: this call is the reset() of a finished episode
+    if (lane < NP) prow[lane] = lane < pv.N ? reinterpret_cast<const int16_t*>(pv.init)[lane] : int16_t(0);
+    if (lane == 0) {
+      a.steps[env] = 0;
+      a.term[env] = 0;
+      a.trunc[env] = 0;
+      if (a.reward) a.reward[env] = 0.0;
+      if (a.dgoals) a.dgoals[env] = 0;
+    }
+    return;
+  }
+  if (act > 3) {  // not in Discrete(4): flag and leave the env untouched (gym_env.py:195-196)
+    if (lane == 0) {
+      a.term[env] = 0xFF;
+      a.trunc[env] = 0xFF;
+    }
+    return;
+  }
+
+  // coalesced load of the packed (x, y) int8 pairs: lane j holds object j
+  int xy = 0;
+  if (lane < NP) xy = static_cast<uint16_t>(prow[lane]);
+
+  uint64_t wall = 0, awall = 0;
+  if (lane < pv.H) {
+    wall = pv.wall[lane];
+    awall = pv.awall[lane];
+  }
+  uint64_t row[NP];
+#pragma unroll
+  for (int j = 0; j < NP; j++) {
+    row[j] = 0;
+    if (j < pv.N) {
+      const int pj = __builtin_amdgcn_readlane(xy, j);
+      row[j] = object_row(pv, j, static_cast<int8_t>(pj & 0xff), static_cast<int8_t>((pj >> 8) & 0xff), lane);
+    }
+  }
+
+  const uint32_t pushed = push_closure<NP>(pv, row, wall, awall, xy, act, lane);
+
+  // displaced state (puzzle.py:384-394) + goal bookkeeping (puzzle.py:396-411)
+  const int dx = act == 0 ? -1 : (act == 1 ? 1 : 0);
+  const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
+  int x = static_cast<int8_t>(xy & 0xff), y = static_cast<int8_t>((xy >> 8) & 0xff);
+  const bool is_goal_lane = lane >= 1 && lane <= pv.G;
+  int gxy = 0;
+  if (is_goal_lane) gxy = reinterpret_cast<const uint16_t*>(pv.goal)[lane - 1];
+  const int before = __popcll(__ballot(is_goal_lane && (xy & 0xffff) == gxy));
+  if ((pushed >> lane) & 1u) {
+    x += dx;
+    y += dy;
+  }
+  const int nxy = (x & 0xff) | ((y & 0xff) << 8);
+  const int after = __popcll(__ballot(is_goal_lane && nxy == gxy));
+  if (pushed && lane < pv.N) prow[lane] = static_cast<int16_t>(nxy);
+
+  if (lane == 0) {
+    const bool terminated = after == pv.G;  // vacuously true without goals (trap T8)
+    const int s = a.steps[env] + 1;
+    a.steps[env] = s;
+    a.term[env] = terminated ? 1 : 0;
+    a.trunc[env] = (a.max_steps > 0 && s >= a.max_steps) ? 1 : 0;
+    // gym_env.py:212-221: python float arithmetic == IEEE double here
+    if (a.reward) a.reward[env] = terminated ? 10.0 : static_cast<double>(after - before) - 0.01;
+    if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(after - before);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K3 expand4  (best_first_search.h:76-78 -> pushworld_puzzle.cc:386-469)
+// ------------------------------------------------------------------------------------
+struct ExpandArgs {
+  const PwPuzzleHeader* hdrs;
+  const uint8_t* blob;
+  int32_t puzzle;
+  const int32_t* states;
+  int32_t* succ;
+  uint32_t* moved;
+  uint8_t* goal;
+  int32_t num_states;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void pw_expand4_kernel(ExpandArgs a) {
+  const int lane = threadIdx.x & (PW_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int sidx = blockIdx.x * (256 / PW_WAVE) + wave;
+  if (sidx >= a.num_states) return;
+  const PuzzleView pv = view_of(a.hdrs, a.blob, a.puzzle);
+  const int N = pv.N;
+
+  // Position2D = x * 10000 + y (pushworld_puzzle.h:32-37)
+  int p2d = 0, x = 0, y = 0;
+  if (lane < N) {
+    p2d = a.states[static_cast<int64_t>(sidx) * N + lane];
+    x = p2d / PW_POSITION_LIMIT;
+    y = p2d - x * PW_POSITION_LIMIT;
+  }
+  const int xy = (x & 0xff) | ((y & 0xff) << 8);
+
+  uint64_t wall = 0, awall = 0;
+  if (lane < pv.H) {
+    wall = pv.wall[lane];
+    awall = pv.awall[lane];
+  }
+  uint64_t row[NP];
+#pragma unroll
+  for (int j = 0; j < NP; j++) {
+    row[j] = 0;
+    if (j < N) {
+      const int pj = __builtin_amdgcn_readlane(xy, j);
+      row[j] = object_row(pv, j, static_cast<int8_t>(pj & 0xff), static_cast<int8_t>((pj >> 8) & 0xff), lane);
+    }
+  }
+  const bool is_goal_lane = lane >= 1 && lane <= pv.G;
+  int g2d = 0;
+  if (is_goal_lane) {
+    const int gxy = reinterpret_cast<const uint16_t*>(pv.goal)[lane - 1];
+    g2d = (gxy & 0xff) * PW_POSITION_LIMIT + ((gxy >> 8) & 0xff);
+  }
+
+  for (int act = 0; act < 4; act++) {
+    const uint32_t pushed = push_closure<NP>(pv, row, wall, awall, xy, act, lane);
+    const int disp = act == 0 ? -PW_POSITION_LIMIT : (act == 1 ? PW_POSITION_LIMIT : (act == 2 ? -1 : 1));
+    const int n2d = p2d + (((pushed >> lane) & 1u) ? disp : 0);
+    const int64_t o = static_cast<int64_t>(sidx) * 4 + act;
+    if (lane < N) a.succ[o * N + lane] = n2d;
+    const int hits = __popcll(__ballot(is_goal_lane && n2d == g2d));
+    if (lane == 0) {
+      a.moved[o] = pushed;
+      a.goal[o] = hits == pv.G ? 1 : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K2 render  (puzzle.py:426-469, :596-638; env_utils.py:44-91)
+// ------------------------------------------------------------------------------------
+struct RenderArgs {
+  const PwPuzzleHeader* hdrs;
+  const uint8_t* blob;
+  const int32_t* puzzle_id;
+  const int8_t* pos;
+  uint8_t* obs;
+  int64_t env_stride;
+  int32_t batch;
+  int32_t np;
+  int32_t ppc, bw;
+  int32_t pad_h, pad_w;    // frame in cells
+  int32_t grid_cap;        // LDS capacity of the cell grid (cells)
+  int32_t obs_bytes;       // bytes of one observation
+  uint32_t pal_rgb[16];    // byte0 = R, byte1 = G, byte2 = B
+  float pal_f32[16][4];    // uint8 -> float32 / 255 (env_utils.py:65-72), exact IEEE division
+};
+
+// Which of the three horizontal zones (left border | middle | right border) of zone row zy
+// are border pixels for an absent-neighbour mask (puzzle.py:631-638).  bit zx of the result.
+__device__ __forceinline__ uint32_t zone_border_bits(uint32_t m, int zy) {
+  uint32_t u = 0, cl = 0, cr = 0;
+  if (zy == 0) {
+    u = (m >> 2) & 1u;
+    cl = (m >> 4) & 1u;
+    cr = (m >> 5) & 1u;
+  } else if (zy == 2) {
+    u = (m >> 3) & 1u;
+    cl = (m >> 6) & 1u;
+    cr = (m >> 7) & 1u;
+  }
+  const uint32_t b0 = (m & 1u) | u | cl;
+  const uint32_t b2 = ((m >> 1) & 1u) | u | cr;
+  return b0 | (u << 1) | (b2 << 2);
+}
+
+// Phases A-C shared by all render kernels: build the per-env zone-colour table
+//   E[(3 * cy + zy) * estride + cx + c0]  = colour(zx=0) | colour(zx=1) << 4 | colour(zx=2) << 8
+// in LDS.  `estride` columns per row, the puzzle's own columns start at c0; the remaining
+// entries are PW_C_PAD.
+__device__ __forceinline__ void build_zone_table(const RenderArgs& a, const PuzzleView& pv, int env, uint32_t* grid,
+                                                 uint8_t* gmask, uint16_t* E, int16_t* spos, int estride, int c0) {
+  const int tid = threadIdx.x;
+  const int W = pv.W, H = pv.H;
+  const int cells = W * H;
+  if (tid < a.np) spos[tid] = reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + tid];
+  for (int i = tid; i < cells; i += blockDim.x) {
+    const uint32_t code = pv.stat[i];
+    grid[i] = code & 0x00FFFFFFu;
+    gmask[i] = static_cast<uint8_t>(code >> PW_CODE_GOAL_SHIFT);
+  }
+  __syncthreads();
+  // movables in painter order (puzzle.py:457): a higher object index wins a shared cell
+  for (int m = tid; m < pv.n_mcells; m += blockDim.x) {
+    const uint32_t c = pv.mcells[m];
+    const int obj = c >> 24;
+    const int p = static_cast<uint16_t>(spos[obj]);
+    const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
+    const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
+    const uint32_t kind = obj == 0 ? 3u : (obj <= pv.G ? 4u : 5u);
+    const uint32_t val = (static_cast<uint32_t>(obj + 1) << PW_CODE_PRIO_SHIFT) | (kind << PW_CODE_KIND_SHIFT) | ((c >> 16) & 0xffu);
+    if (static_cast<unsigned>(x) < static_cast<unsigned>(W) && static_cast<unsigned>(y) < static_cast<unsigned>(H))
+      atomicMax(&grid[y * W + x], val);
+  }
+  __syncthreads();
+  const int ecells = H * estride;
+  for (int i = tid; i < ecells; i += blockDim.x) {
+    const int cy = i / estride;
+    const int cv = i - cy * estride;
+    const int cx = cv - c0;
+    uint32_t e0 = 0, e1 = 0, e2 = 0;
+    if (static_cast<unsigned>(cx) < static_cast<unsigned>(W)) {
+      const uint32_t code = grid[cy * W + cx];
+      const uint32_t gm = gmask[cy * W + cx];
+      const uint32_t kind = (code >> PW_CODE_KIND_SHIFT) & 0xfu;
+      const uint32_t fill = kind ? 2u * kind : static_cast<uint32_t>(PW_C_BACKGROUND);
+      const uint32_t edge = kind ? 2u * kind + 1u : static_cast<uint32_t>(PW_C_BACKGROUND);
+      const uint32_t om = code & 0xffu;
+      uint32_t ent[3];
+#pragma unroll
+      for (int zy = 0; zy < 3; zy++) {
+        const uint32_t ob = zone_border_bits(om, zy);
+        const uint32_t gb = zone_border_bits(gm, zy);
+        uint32_t v = 0;
+#pragma unroll
+        for (int zx = 0; zx < 3; zx++) {
+          uint32_t col = ((ob >> zx) & 1u) ? edge : fill;
+          if ((gb >> zx) & 1u) col = PW_C_GOAL_BORDER;
+          v |= col << (4 * zx);
+        }
+        ent[zy] = v;
+      }
+      e0 = ent[0];
+      e1 = ent[1];
+      e2 = ent[2];
+    }
+    E[(3 * cy + 0) * estride + cv] = static_cast<uint16_t>(e0);
+    E[(3 * cy + 1) * estride + cv] = static_cast<uint16_t>(e1);
+    E[(3 * cy + 2) * estride + cv] = static_cast<uint16_t>(e2);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void carve_lds(const RenderArgs& a, unsigned char* smem, uint32_t*& grid, uint16_t*& E,
+                                          uint8_t*& gmask, int16_t*& spos, uint32_t*& pal) {
+  grid = reinterpret_cast<uint32_t*>(smem);
+  pal = grid + a.grid_cap;
+  spos = reinterpret_cast<int16_t*>(pal + 16);
+  gmask = reinterpret_cast<uint8_t*>(spos + 32);
+  E = reinterpret_cast<uint16_t*>(gmask + ((a.grid_cap + 15) & ~15));
+}
+
+// Fast path: uint8 observation, pixels_per_cell = 3, border_width = 1 (zones == pixels).
+// A zone-table entry is then exactly 3 pixels = 9 bytes of one image row, and because the
+// frame is pad_w * 3 pixels wide the table (row stride pad_w) is the image itself in
+// 9-byte units: output byte o belongs to entry floor((o - shift) / 9).
+__global__ __launch_bounds__(256) void pw_render_u8_ppc3_kernel(RenderArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* grid;
+  uint16_t* E;
+  uint8_t* gmask;
+  int16_t* spos;
+  uint32_t* pal;
+  carve_lds(a, smem, grid, E, gmask, spos, pal);
+  const int env = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int pid = a.puzzle_id[env];
+  const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
+  if (tid < 16) pal[tid] = a.pal_rgb[tid];
+
+  // pixel padding of env_utils.py:75-91 (left/top get the floor half)
+  const int wpx = a.pad_w * 3;
+  const int pady = (a.pad_h - pv.H) * 3 / 2;
+  const int padx = (a.pad_w - pv.W) * 3 / 2;
+  const int c0 = (padx + 2) / 3;  // virtual cell columns left of the puzzle
+  build_zone_table(a, pv, env, grid, gmask, E, spos, a.pad_w, c0);
+
+  const int n_entries = 3 * pv.H * a.pad_w;
+  const int shift_bytes = 3 * (pady * wpx + padx - 3 * c0);  // may be negative by < 9 bytes per row
+  // bias keeps the dividend non-negative; multiple of 9
+  const int bias_q = (shift_bytes > 0 ? shift_bytes / 9 : 0) + 2;
+  const int n_chunks = (a.obs_bytes + 15) >> 4;
+  uint8_t* out = a.obs + static_cast<int64_t>(env) * a.env_stride;
+
+  for (int chunk = tid; chunk < n_chunks; chunk += 256) {
+    const unsigned o3 = static_cast<unsigned>(chunk * 16 - shift_bytes + 9 * bias_q);
+    const unsigned qb = o3 / 9u;
+    const int b = static_cast<int>(o3 - qb * 9u);
+    const int q0 = static_cast<int>(qb) - bias_q;
+    uint32_t e[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int q = q0 + k;
+      e[k] = (static_cast<unsigned>(q) < static_cast<unsigned>(n_entries)) ? E[q] : 0u;
+    }
+    // 9-byte pixel triples -> 64-bit words
+    uint64_t lo[3];
+    uint32_t hi[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const uint64_t r0 = pal[e[k] & 15u], r1 = pal[(e[k] >> 4) & 15u];
+      if (k < 2) {
+        const uint64_t r2 = pal[(e[k] >> 8) & 15u];
+        lo[k] = r0 | (r1 << 24) | (r2 << 48);
+        hi[k] = static_cast<uint32_t>(r2 >> 16);
+      } else {
+        lo[k] = r0 | (r1 << 24);
+      }
+    }
+    // bytes 0..23 of the concatenation, then a byte-granular funnel shift by b (0..8)
+    const uint64_t A = lo[0];
+    const uint64_t B = static_cast<uint64_t>(hi[0]) | (lo[1] << 8);
+    const uint64_t C = (lo[1] >> 56) | (static_cast<uint64_t>(hi[1]) << 8) | (lo[2] << 16);
+    uint64_t w0, w1;
+    if (b == 8) {
+      w0 = B;
+      w1 = C;
+    } else if (b == 0) {
+      w0 = A;
+      w1 = B;
+    } else {
+      const int sh = 8 * b;
+      w0 = (A >> sh) | (B << (64 - sh));
+      w1 = (B >> sh) | (C << (64 - sh));
+    }
+    uint4 v;
+    v.x = static_cast<uint32_t>(w0);
+    v.y = static_cast<uint32_t>(w0 >> 32);
+    v.z = static_cast<uint32_t>(w1);
+    v.w = static_cast<uint32_t>(w1 >> 32);
+    *reinterpret_cast<uint4*>(out + static_cast<int64_t>(chunk) * 16) = v;
+  }
+}
+
+// Generic path: any pixels_per_cell / border_width, uint8 or float32 elements.
+// One thread produces 16 bytes (16 uint8 or 4 float32 channel values) per iteration.
+template <typename T>
+__global__ __launch_bounds__(256) void pw_render_generic_kernel(RenderArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* grid;
+  uint16_t* E;
+  uint8_t* gmask;
+  int16_t* spos;
+  uint32_t* pal;
+  carve_lds(a, smem, grid, E, gmask, spos, pal);
+  const int env = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int pid = a.puzzle_id[env];
+  const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
+  if (tid < 16) pal[tid] = a.pal_rgb[tid];
+  build_zone_table(a, pv, env, grid, gmask, E, spos, pv.W, 0);
+
+  constexpr int kElems = 16 / sizeof(T);
+  const int ppc = a.ppc, bw = a.bw;
+  const int wpx = a.pad_w * ppc;
+  const int own_w = pv.W * ppc, own_h = pv.H * ppc;
+  const int pady = (a.pad_h * ppc - own_h) / 2;
+  const int padx = (wpx - own_w) / 2;
+  const int n_chunks = (a.obs_bytes + 15) >> 4;
+  uint8_t* out = a.obs + static_cast<int64_t>(env) * a.env_stride;
+
+  for (int chunk = tid; chunk < n_chunks; chunk += 256) {
+    const int elem0 = chunk * kElems;
+    int pix = elem0 / 3;
+    int ch = elem0 - pix * 3;
+    int Y = pix / wpx;
+    int X = pix - Y * wpx;
+    uint32_t col = 0;
+    bool have = false;
+    union {
+      uint4 v;
+      uint8_t u8[16];
+      float f32[4];
+    } o;
+#pragma unroll
+    for (int k = 0; k < kElems; k++) {
+      if (!have) {
+        const int yp = Y - pady, xp = X - padx;
+        col = PW_C_PAD;
+        if (static_cast<unsigned>(yp) < static_cast<unsigned>(own_h) &&
+            static_cast<unsigned>(xp) < static_cast<unsigned>(own_w)) {
+          const int cy = yp / ppc, sy = yp - cy * ppc;
+          const int cx = xp / ppc, sx = xp - cx * ppc;
+          const int zy = sy < bw ? 0 : (sy >= ppc - bw ? 2 : 1);
+          const int zx = sx < bw ? 0 : (sx >= ppc - bw ? 2 : 1);
+          col = (E[(3 * cy + zy) * pv.W + cx] >> (4 * zx)) & 15u;
+        }
+        have = true;
+      }
+      if (sizeof(T) == 1)
+        o.u8[k] = static_cast<uint8_t>(pal[col] >> (8 * ch));
+      else
+        o.f32[k] = a.pal_f32[col][ch];
+      if (++ch == 3) {
+        ch = 0;
+        have = false;
+        if (++X == wpx) {
+          X = 0;
+          Y++;
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(out + static_cast<int64_t>(chunk) * 16) = o.v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// engine half of the C ABI
+// ------------------------------------------------------------------------------------
+namespace {
+
+const uint8_t kPaletteRGB[PW_NUM_COLORS][3] = {
+    {0, 0, 0},           // PW_C_PAD
+    {255, 255, 255},     // PW_C_BACKGROUND      puzzle.py:451
+    {0xFA, 0xC7, 0x1E},  // AGENT_WALL           puzzle.py:70
+    {0x7D, 0x64, 0x0F},  // AGENT_WALL_BORDER    :71
+    {0x0A, 0x0A, 0x0A},  // WALL                 :78
+    {0x05, 0x05, 0x05},  // WALL_BORDER          :79
+    {0x00, 0xDC, 0x00},  // AGENT                :68
+    {0x00, 0x6E, 0x00},  // AGENT_BORDER         :69
+    {0xDC, 0x00, 0x00},  // GOAL_OBJECT          :74
+    {0x6E, 0x00, 0x00},  // GOAL_OBJECT_BORDER   :75
+    {0x46, 0x9B, 0xFF},  // MOVABLE              :76
+    {0x23, 0x48, 0x7F},  // MOVABLE_BORDER       :77
+    {0xB9, 0x00, 0x00},  // GOAL_BORDER          :73
+};
+
+int check_launch(const char* what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pw_fail(PW_EDEVICE, std::string(what) + ": " + hipGetErrorString(err));
+  return PW_OK;
+}
+
+int fill_render_args(const PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs, int64_t stride,
+                     int32_t batch, RenderArgs* ra) {
+  if (!puzzle_id || !pos || !obs) return pw_fail(PW_EINVAL, "null device pointer");
+  if (stride < e->obs_bytes || (stride & 15)) return pw_fail(PW_EINVAL, "env_stride_bytes must be >= obs bytes rounded up to 16 and a multiple of 16");
+  if (stride < ((e->obs_bytes + 15) & ~int64_t(15))) return pw_fail(PW_EINVAL, "env_stride_bytes too small");
+  if (reinterpret_cast<uintptr_t>(obs) & 15) return pw_fail(PW_EINVAL, "obs must be 16-byte aligned");
+  ra->hdrs = e->set->d_headers;
+  ra->blob = e->set->d_blob;
+  ra->puzzle_id = puzzle_id;
+  ra->pos = pos;
+  ra->obs = static_cast<uint8_t*>(obs);
+  ra->env_stride = stride;
+  ra->batch = batch;
+  ra->np = e->np;
+  ra->ppc = e->cfg.pixels_per_cell;
+  ra->bw = e->cfg.border_width;
+  ra->pad_h = e->pad_h;
+  ra->pad_w = e->pad_w;
+  ra->grid_cap = e->set->max_w * e->set->max_h;
+  ra->obs_bytes = static_cast<int32_t>(e->obs_bytes);
+  for (int i = 0; i < 16; i++) {
+    ra->pal_rgb[i] = e->pal_rgb[i];
+    for (int c = 0; c < 4; c++) ra->pal_f32[i][c] = e->pal_f32[i][c];
+  }
+  return PW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine** out) {
+  if (!s || !cfg || !out) return pw_fail(PW_EINVAL, "null argument");
+  if (s->device < 0 || !s->d_blob) return pw_fail(PW_EDEVICE, "puzzle set has no device tables (created with device < 0)");
+  if (cfg->border_width < 1) return pw_fail(PW_EINVAL, "border_width must be >= 1");
+  if (cfg->pixels_per_cell < 3) return pw_fail(PW_EINVAL, "pixels_per_cell must be >= 3");
+  if (cfg->pixels_per_cell < 1 + 2 * cfg->border_width)
+    return pw_fail(PW_EINVAL, "pixels_per_cell must be >= 1 + 2*border_width");
+  if (cfg->obs_dtype != PW_OBS_U8 && cfg->obs_dtype != PW_OBS_F32) return pw_fail(PW_EINVAL, "bad obs_dtype");
+  PwEngine* e = new (std::nothrow) PwEngine();
+  if (!e) return pw_fail(PW_ENOMEM, "out of memory");
+  e->set = s;
+  e->cfg = *cfg;
+  e->np = s->max_n <= 4 ? 4 : (s->max_n <= 8 ? 8 : (s->max_n <= 16 ? 16 : 32));
+  e->pad_h = cfg->pad_cell_height > 0 ? cfg->pad_cell_height : s->max_h;
+  e->pad_w = cfg->pad_cell_width > 0 ? cfg->pad_cell_width : s->max_w;
+  if (e->pad_h < s->max_h || e->pad_w < s->max_w) {
+    delete e;
+    return pw_fail(PW_EINVAL, "observation frame is smaller than the largest puzzle in the set");
+  }
+  e->obs_h = e->pad_h * cfg->pixels_per_cell;
+  e->obs_w = e->pad_w * cfg->pixels_per_cell;
+  e->obs_bytes = static_cast<int64_t>(e->obs_h) * e->obs_w * 3 * (cfg->obs_dtype == PW_OBS_F32 ? 4 : 1);
+  if (e->obs_bytes > (int64_t(1) << 30)) {
+    delete e;
+    return pw_fail(PW_ELIMIT, "observation larger than 1 GiB");
+  }
+  const int cells = s->max_w * s->max_h;
+  // grid u32[cells] + pal u32[16] + spos i16[32] + gmask u8[cells, 16-aligned] + E u16[3 * max_h * pad_w]
+  e->render_lds = static_cast<size_t>(cells) * 4 + 64 + 64 + ((cells + 15) & ~15) +
+                  static_cast<size_t>(3) * s->max_h * e->pad_w * 2 + 16;
+  for (int i = 0; i < 16; i++) {
+    e->pal_rgb[i] = 0;
+    for (int c = 0; c < 4; c++) e->pal_f32[i][c] = 0.0f;
+  }
+  for (int i = 0; i < PW_NUM_COLORS; i++) {
+    e->pal_rgb[i] = kPaletteRGB[i][0] | (kPaletteRGB[i][1] << 8) | (kPaletteRGB[i][2] << 16);
+    for (int c = 0; c < 3; c++) {
+      // env_utils.py:65-72: uint8.astype(float32) / 255 -- one correctly rounded binary32 division
+      volatile float num = static_cast<float>(kPaletteRGB[i][c]);
+      volatile float den = 255.0f;
+      e->pal_f32[i][c] = num / den;
+    }
+  }
+  hipError_t err = hipSetDevice(s->device);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_u8_ppc3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_generic_kernel<uint8_t>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_generic_kernel<float>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
+  if (err != hipSuccess) {
+    delete e;
+    return pw_fail(PW_EDEVICE, std::string("engine setup failed: ") + hipGetErrorString(err));
+  }
+  *out = e;
+  return PW_OK;
+}
+
+void pw_engine_destroy(PwEngine* e) { delete e; }
+
+int pw_engine_npad(const PwEngine* e) { return e ? e->np : pw_fail(PW_EINVAL, "null engine"); }
+
+int pw_engine_obs_shape(const PwEngine* e, int* h, int* w, int* c) {
+  if (!e) return pw_fail(PW_EINVAL, "null engine");
+  if (h) *h = e->obs_h;
+  if (w) *w = e->obs_w;
+  if (c) *c = 3;
+  return PW_OK;
+}
+
+int64_t pw_engine_obs_bytes(const PwEngine* e) { return e ? e->obs_bytes : pw_fail(PW_EINVAL, "null engine"); }
+
+int64_t pw_engine_obs_stride(const PwEngine* e) {
+  if (!e) return pw_fail(PW_EINVAL, "null engine");
+  return (e->obs_bytes + 255) & ~int64_t(255);
+}
+
+int pw_reset(PwEngine* e, const int32_t* puzzle_id, const uint8_t* mask, int8_t* pos, int32_t* steps,
+             uint8_t* terminated, uint8_t* truncated, int32_t batch, void* stream) {
+  if (!e || !puzzle_id || !pos || !steps) return pw_fail(PW_EINVAL, "null argument");
+  if (batch <= 0) return PW_OK;
+  ResetArgs a{e->set->d_headers, e->set->d_blob, puzzle_id, mask, pos, steps, terminated, truncated, batch, e->np};
+  const int64_t threads = static_cast<int64_t>(batch) * e->np;
+  const unsigned blocks = static_cast<unsigned>((threads + 255) / 256);
+  hipLaunchKernelGGL(pw_reset_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("pw_reset");
+}
+
+int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,
+            double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, int32_t batch,
+            uint32_t flags, void* stream) {
+  if (!e || !puzzle_id || !actions || !pos || !steps || !terminated || !truncated)
+    return pw_fail(PW_EINVAL, "null argument");
+  if (batch <= 0) return PW_OK;
+  StepArgs a{e->set->d_headers, e->set->d_blob, puzzle_id, actions, pos, steps, reward, dgoals,
+             terminated, truncated, batch, e->cfg.max_steps, flags};
+  const unsigned blocks = static_cast<unsigned>((batch + 3) / 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (e->np) {
+    case 4: hipLaunchKernelGGL(pw_step_kernel<4>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(pw_step_kernel<8>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(pw_step_kernel<16>, dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(pw_step_kernel<32>, dim3(blocks), dim3(256), 0, st, a); break;
+  }
+  return check_launch("pw_step");
+}
+
+int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs, int64_t env_stride_bytes,
+              int32_t batch, void* stream) {
+  if (!e) return pw_fail(PW_EINVAL, "null engine");
+  if (batch <= 0) return PW_OK;
+  RenderArgs ra;
+  int rc = fill_render_args(e, puzzle_id, pos, obs, env_stride_bytes, batch, &ra);
+  if (rc != PW_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(batch)), block(256);
+  if (e->cfg.obs_dtype == PW_OBS_U8 && e->cfg.pixels_per_cell == 3 && e->cfg.border_width == 1)
+    hipLaunchKernelGGL(pw_render_u8_ppc3_kernel, grid, block, e->render_lds, st, ra);
+  else if (e->cfg.obs_dtype == PW_OBS_U8)
+    hipLaunchKernelGGL(pw_render_generic_kernel<uint8_t>, grid, block, e->render_lds, st, ra);
+  else
+    hipLaunchKernelGGL(pw_render_generic_kernel<float>, grid, block, e->render_lds, st, ra);
+  return check_launch("pw_render");
+}
+
+int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,
+                   double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, void* obs,
+                   int64_t env_stride_bytes, int32_t batch, uint32_t flags, void* stream) {
+  int rc = pw_step(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, batch, flags, stream);
+  if (rc != PW_OK) return rc;
+  return pw_render(e, puzzle_id, pos, obs, env_stride_bytes, batch, stream);
+}
+
+int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ, uint32_t* moved, uint8_t* goal,
+               int32_t num_states, void* stream) {
+  if (!e || !states || !succ || !moved || !goal) return pw_fail(PW_EINVAL, "null argument");
+  if (puzzle < 0 || puzzle >= e->set->count) return pw_fail(PW_EINVAL, "puzzle index out of range");
+  if (num_states <= 0) return PW_OK;
+  ExpandArgs a{e->set->d_headers, e->set->d_blob, puzzle, states, succ, moved, goal, num_states};
+  const unsigned blocks = static_cast<unsigned>((num_states + 3) / 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (e->np) {
+    case 4: hipLaunchKernelGGL(pw_expand4_kernel<4>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(pw_expand4_kernel<8>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(pw_expand4_kernel<16>, dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(pw_expand4_kernel<32>, dim3(blocks), dim3(256), 0, st, a); break;
+  }
+  return check_launch("pw_expand4");
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+"""``PushWorldPuzzle`` with the reference's Python surface, executed on an MI355X.
+
+Mirrors ``python3/src/pushworld/puzzle.py`` of google-deepmind/pushworld (class surface
+:100-128, properties :313-346, methods :348-506) so user code and the reference's own tests
+can switch imports.  Parsing happens in the C++ host library, dynamics and rendering in the
+HIP kernels of ``libpushworld_amd.so``; there is no CPU implementation of either -- calling
+``get_next_state`` / ``render`` without a visible HIP device raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Set, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+
+# puzzle.py:22-29
+DEFAULT_BORDER_WIDTH = 2
+DEFAULT_PIXELS_PER_CELL = 20
+NUM_ACTIONS = 4
+AGENT_IDX = 0
+
+Point = Tuple[int, int]
+State = Tuple[Point, ...]
+Color = Tuple[int, int, int]
+
+
+class Actions:
+    """puzzle.py:32-50."""
+
+    LEFT, RIGHT, UP, DOWN = range(NUM_ACTIONS)
+    FROM_CHAR = {"L": LEFT, "R": RIGHT, "U": UP, "D": DOWN}
+    DISPLACEMENTS = np.array([(-1, 0), (1, 0), (0, -1), (0, 1)])
+
+
+def hex_to_rgb(hex_string: str) -> Color:
+    return tuple(int(hex_string[i : i + 2], 16) for i in (0, 2, 4))
+
+
+class Colors:
+    """puzzle.py:65-79 (the kernels carry the same palette, csrc/pw_kernels.hip)."""
+
+    AGENT = hex_to_rgb("00DC00")
+    AGENT_BORDER = hex_to_rgb("006E00")
+    AGENT_WALL = hex_to_rgb("FAC71E")
+    AGENT_WALL_BORDER = hex_to_rgb("7D640F")
+    GOAL = None
+    GOAL_BORDER = hex_to_rgb("B90000")
+    GOAL_OBJECT = hex_to_rgb("DC0000")
+    GOAL_OBJECT_BORDER = hex_to_rgb("6E0000")
+    MOVABLE = hex_to_rgb("469BFF")
+    MOVABLE_BORDER = hex_to_rgb("23487F")
+    WALL = hex_to_rgb("0A0A0A")
+    WALL_BORDER = hex_to_rgb("050505")
+
+
+@dataclass(frozen=True)
+class PushWorldObject:
+    """puzzle.py:82-97."""
+
+    position: Point
+    fill_color: Optional[Color]
+    border_color: Color
+    cells: Set[Point]
+
+
+def default_device_index() -> int:
+    """HIP device used by the single-environment wrappers (``PUSHWORLD_AMD_DEVICE``)."""
+    if "PUSHWORLD_AMD_DEVICE" in os.environ:
+        return int(os.environ["PUSHWORLD_AMD_DEVICE"])
+    if not torch.cuda.is_available() or _capi.device_count() == 0:
+        raise RuntimeError(
+            "pushworld_amd needs a HIP device (MI355X / gfx950); none is visible and there is no CPU fallback"
+        )
+    return torch.cuda.current_device()
+
+
+def _as_state(state) -> State:
+    return tuple((int(p[0]), int(p[1])) for p in state)
+
+
+class PushWorldPuzzle:
+    """A puzzle in the PushWorld environment (reference surface, GPU execution).
+
+    Args:
+        file_path: path of a ``.pwp`` file.
+        text: alternatively the file contents (keyword only).
+        order: ``"python"`` (default, puzzle.py object order) or ``"cpp"``
+            (pushworld_puzzle.cc object order), see SURVEY trap T1.
+    """
+
+    def __init__(self, file_path: Optional[str] = None, *, text: Optional[str] = None, order: str = "python"):
+        if text is None:
+            with open(file_path, "r") as fi:
+                text = fi.read()
+        self.file_path = file_path
+        self._text = text
+        self._parsed = _capi.ParsedPuzzle(text, _capi.ORDER_PYTHON if order == "python" else _capi.ORDER_CPP)
+        p = self._parsed
+        self._width, self._height = p.width, p.height
+        self.num_movables = p.num_movables
+        self._initial_state: State = p.initial_state
+        self._goal_state = p.goal_state
+        self._wall_positions = set(p.wall_cells)
+        # trap T2: the reference property returns AW u W (puzzle.py:253,273,338-341)
+        self._agent_wall_positions = set(p.agent_wall_cells) | self._wall_positions
+        g = p.num_goals
+        self._movable_objects = []
+        for j in range(p.num_movables):
+            if j == 0:
+                fill, border = Colors.AGENT, Colors.AGENT_BORDER
+            elif j <= g:
+                fill, border = Colors.GOAL_OBJECT, Colors.GOAL_OBJECT_BORDER
+            else:
+                fill, border = Colors.MOVABLE, Colors.MOVABLE_BORDER
+            self._movable_objects.append(
+                PushWorldObject(position=p.initial_state[j], fill_color=fill, border_color=border,
+                                cells=set(p.object_cells[j]))
+            )
+        self._goals = [
+            PushWorldObject(position=p.goal_state[k], fill_color=Colors.GOAL, border_color=Colors.GOAL_BORDER,
+                            cells=set(p.goal_cells[k]))
+            for k in range(g)
+        ]
+        self._pset = None
+        self._engines = {}
+        self._bufs = None
+
+    # ---------------------------------------------------------------- properties
+    @property
+    def initial_state(self) -> State:
+        return self._initial_state
+
+    @property
+    def goal_state(self) -> Tuple[Point, ...]:
+        return self._goal_state
+
+    @property
+    def dimensions(self) -> Tuple[int, int]:
+        return (self._width, self._height)
+
+    @property
+    def wall_positions(self) -> Set[Point]:
+        return self._wall_positions
+
+    @property
+    def agent_wall_positions(self) -> Set[Point]:
+        return self._agent_wall_positions
+
+    @property
+    def movable_objects(self) -> List[PushWorldObject]:
+        return self._movable_objects
+
+    # ---------------------------------------------------------------- device plumbing
+    def _puzzle_set(self) -> "_capi.PuzzleSet":
+        if self._pset is None:
+            self._pset = _capi.PuzzleSet([self._parsed], default_device_index())
+        return self._pset
+
+    def _engine(self, ppc=3, bw=1, dtype=_capi.OBS_U8) -> "_capi.Engine":
+        key = (ppc, bw, dtype)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _capi.Engine(self._puzzle_set(), None, ppc, bw, dtype)
+            self._engines[key] = eng
+        return eng
+
+    def _state_bufs(self, eng):
+        if self._bufs is None:
+            self._bufs = eng.alloc_state(1)
+            self._bufs["pid"] = torch.zeros((1,), dtype=torch.int32, device=eng.device)
+            self._bufs["act"] = torch.zeros((1,), dtype=torch.uint8, device=eng.device)
+        return self._bufs
+
+    def _upload(self, eng, state) -> None:
+        state = _as_state(state)
+        if len(state) != self.num_movables:
+            raise ValueError(f"state has {len(state)} positions, puzzle has {self.num_movables} movables")
+        host = torch.zeros((1, eng.np, 2), dtype=torch.int8)
+        host[0, : self.num_movables] = torch.tensor(state, dtype=torch.int8)
+        self._state_bufs(eng)["pos"].copy_(host)
+
+    def _download(self, eng) -> State:
+        arr = self._bufs["pos"][0, : self.num_movables].cpu().tolist()
+        return tuple((int(x), int(y)) for x, y in arr)
+
+    # ---------------------------------------------------------------- dynamics
+    def get_next_state(self, state: State, action: int) -> State:
+        """puzzle.py:348-394 on the GPU (one wavefront)."""
+        if action not in (0, 1, 2, 3):
+            raise ValueError("action must be one of 0 (L), 1 (R), 2 (U), 3 (D)")
+        eng = self._engine()
+        b = self._state_bufs(eng)
+        self._upload(eng, state)
+        b["act"].fill_(int(action))
+        eng.step(b["pid"], b["act"], b["pos"], b["steps"], b["reward"], b["dgoals"], b["terminated"], b["truncated"])
+        return self._download(eng)
+
+    def count_achieved_goals(self, state: State) -> int:
+        """puzzle.py:396-407 (a host-side comparison of caller-owned tuples; the batched
+        engine computes the same count on the device for its reward)."""
+        return sum(1 for s, g in zip(state[1 : 1 + len(self._goal_state)], self._goal_state) if tuple(s) == g)
+
+    def is_goal_state(self, state: State) -> bool:
+        """puzzle.py:409-411."""
+        return _as_state(state[1 : 1 + len(self._goal_state)]) == self._goal_state
+
+    def is_valid_plan(self, plan: Iterable[int]) -> bool:
+        """puzzle.py:413-424: the whole plan is replayed on the device; a plan that reaches
+        the goal before its last action is rejected like in the reference."""
+        plan = [int(a) for a in plan]
+        if self.is_goal_state(self._initial_state):
+            return len(plan) == 0
+        if not plan:
+            return False
+        eng = self._engine()
+        b = self._state_bufs(eng)
+        self._upload(eng, self._initial_state)
+        acts = torch.tensor(plan, dtype=torch.uint8).to(eng.device)
+        term = torch.zeros((len(plan),), dtype=torch.uint8, device=eng.device)
+        for t in range(len(plan)):
+            eng.step(b["pid"], acts[t : t + 1], b["pos"], b["steps"], b["reward"], b["dgoals"], term[t : t + 1],
+                     b["truncated"])
+        hist = term.cpu().numpy()
+        return bool(hist[-1] == 1 and not hist[:-1].any())
+
+    # ---------------------------------------------------------------- rendering
+    def render(self, state: State, border_width: int = DEFAULT_BORDER_WIDTH,
+               pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL) -> np.ndarray:
+        """puzzle.py:426-469 on the GPU; uint8 (height, width, 3)."""
+        if border_width < 1:
+            raise ValueError("border_width must be >= 1")
+        if pixels_per_cell < 1 + 2 * border_width:
+            raise ValueError("pixels_per_cell must be >= 1 + 2*border_width")
+        return self._render_device(state, border_width, pixels_per_cell, _capi.OBS_U8).cpu().numpy()
+
+    def _render_device(self, state, border_width, pixels_per_cell, dtype) -> torch.Tensor:
+        eng = self._engine(pixels_per_cell, border_width, dtype)
+        b = self._state_bufs(eng)
+        self._upload(eng, state)
+        key = ("obs", pixels_per_cell, border_width, dtype)
+        if key not in self._bufs:
+            self._bufs[key] = eng.alloc_obs(1)
+        storage, view = self._bufs[key]
+        eng.render(b["pid"], b["pos"], storage)
+        return view[0]
+
+    def render_plan(self, plan: Iterable[int], border_width: int = DEFAULT_BORDER_WIDTH,
+                    pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL) -> List[np.ndarray]:
+        """puzzle.py:471-506."""
+        state = self._initial_state
+        images = [self.render(state, border_width, pixels_per_cell)]
+        for action in plan:
+            state = self.get_next_state(state, action)
+            images.append(self.render(state, border_width, pixels_per_cell))
+        return images

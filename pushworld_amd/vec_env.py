@@ -1,0 +1,127 @@
+"""Batched PushWorld environments on one MI355X.
+
+``VecPushWorld`` is the batched form of the reference's ``PushWorldEnv.step/reset``
+(python3/src/pushworld/gym_env.py:150-226): B independent environments, each bound to one
+puzzle of a pool, stepped by one kernel launch (+ one render launch).  All state lives in
+HBM as torch tensors; nothing is copied to the host per step.
+
+Semantics per environment are exactly the reference's: no implicit reset after
+termination (trap T9) unless ``autoreset=True`` (next-step autoreset, gymnasium's vector
+convention: the call after a finished episode resets that environment and returns reward 0).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _capi
+from .puzzle import DEFAULT_BORDER_WIDTH, DEFAULT_PIXELS_PER_CELL, PushWorldPuzzle, default_device_index
+
+
+class VecPushWorld:
+    """B environments over a pool of puzzles.
+
+    Args:
+        puzzles: sequence of ``PushWorldPuzzle`` objects or ``.pwp`` paths (the pool).
+        num_envs: B.
+        puzzle_ids: int array [B] of pool indices (default: ``i % len(puzzles)``).  Grouping
+            equal ids together keeps a workgroup's puzzle tables hot in L1/L2.
+        max_steps: truncation limit (gym_env.py:223) or None.
+        observation: "uint8", "float32" or None (state only, no render kernel).
+        pad_cells: (height, width) of the observation frame in cells; default = pool maximum
+            (gym_env.py:80-82).
+        autoreset: next-step autoreset inside the step kernel.
+    """
+
+    def __init__(self, puzzles: Sequence[Union[str, PushWorldPuzzle]], num_envs: int,
+                 puzzle_ids: Optional[Sequence[int]] = None, max_steps: Optional[int] = None,
+                 border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
+                 observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
+                 autoreset: bool = False):
+        self.puzzles = [p if isinstance(p, PushWorldPuzzle) else PushWorldPuzzle(p) for p in puzzles]
+        if not self.puzzles:
+            raise ValueError("No PushWorld puzzles given")
+        if observation not in ("uint8", "float32", None):
+            raise ValueError("observation must be 'uint8', 'float32' or None")
+        dev = default_device_index() if device is None else int(device)
+        self.pset = _capi.PuzzleSet([p._parsed for p in self.puzzles], dev)
+        ph, pw = pad_cells if pad_cells is not None else (0, 0)
+        dtype = _capi.OBS_F32 if observation == "float32" else _capi.OBS_U8
+        self.engine = _capi.Engine(self.pset, max_steps, pixels_per_cell, border_width, dtype, ph, pw)
+        self.device = self.engine.device
+        self.num_envs = int(num_envs)
+        self.observation = observation
+        self.flags = _capi.STEP_AUTORESET if autoreset else 0
+
+        if puzzle_ids is None:
+            ids = np.arange(self.num_envs) % len(self.puzzles)
+        else:
+            ids = np.asarray(puzzle_ids)
+            if ids.shape != (self.num_envs,) or ids.min() < 0 or ids.max() >= len(self.puzzles):
+                raise ValueError("puzzle_ids must be [num_envs] indices into the puzzle pool")
+        self.puzzle_id = torch.as_tensor(ids, dtype=torch.int32).to(self.device)
+        st = self.engine.alloc_state(self.num_envs)
+        self.pos, self.steps = st["pos"], st["steps"]
+        self.reward, self.dgoals = st["reward"], st["dgoals"]
+        self.terminated, self.truncated = st["terminated"], st["truncated"]
+        if observation is not None:
+            self._obs_storage, self.obs = self.engine.alloc_obs(self.num_envs)
+        else:
+            self._obs_storage, self.obs = None, None
+        self._has_reset = False
+
+    # --------------------------------------------------------------------------------
+    @property
+    def num_objects_padded(self) -> int:
+        return self.engine.np
+
+    def set_puzzle_ids(self, puzzle_ids) -> None:
+        self.puzzle_id.copy_(torch.as_tensor(np.asarray(puzzle_ids), dtype=torch.int32))
+
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        """gym_env.py:150-186 for every (masked) environment; returns the observation tensor."""
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8)
+        self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, mask)
+        self._has_reset = True
+        if self.obs is not None:
+            self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+        return self.obs
+
+    def step(self, actions: torch.Tensor):
+        """gym_env.py:188-226 for every environment.
+
+        Args:
+            actions: uint8 tensor [B] on the device with values in 0..3.
+
+        Returns ``(obs, reward float64[B], terminated uint8[B], truncated uint8[B])`` --
+        views of the engine's persistent HBM buffers (overwritten by the next call).
+        """
+        if not self._has_reset:
+            raise RuntimeError("reset() must be called before step() can be called.")
+        if actions.dtype != torch.uint8 or actions.device != self.device or actions.shape != (self.num_envs,):
+            raise ValueError("actions must be a uint8 tensor of shape [num_envs] on the engine's device")
+        if self.obs is not None:
+            self.engine.step_render(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
+                                    self.terminated, self.truncated, self._obs_storage, self.flags)
+        else:
+            self.engine.step(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
+                             self.terminated, self.truncated, self.flags)
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def render(self):
+        """Re-renders the current states into the observation buffer and returns it."""
+        if self.obs is None:
+            raise RuntimeError("this VecPushWorld was created with observation=None")
+        self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+        return self.obs
+
+    def states(self) -> np.ndarray:
+        """Host copy of the positions, int8 [B, NP, 2] (entries past a puzzle's movables are 0)."""
+        return self.pos.cpu().numpy()
+
+    def set_states(self, pos: np.ndarray) -> None:
+        self.pos.copy_(torch.as_tensor(np.asarray(pos), dtype=torch.int8))
+        self._has_reset = True
