@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the batched PushWorld step engine on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload = BASELINE.json config C3, per GPU: 65 536 environments over the 68 Level-1
+puzzles (sorted by file name, environments grouped by puzzle), observation frame padded to
+the Level-1 maximum (51 x 42 cells), RGB render ON every step with pixels_per_cell = 3 /
+border_width = 1 / uint8, max_steps = 200 with next-step autoreset, uniform random actions
+pre-generated on the device.  One "step" = one pass of the hot path over the whole batch:
+the step kernel (dynamics, goal, reward, done) + the render kernel (observation).
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+``roofline`` for the dominant kernel (render; HBM bound) measured live with HIP events on the
+launch stream, and ``cpu_baseline`` = the C restatement of the reference algorithm
+(oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def level1_paths():
+    d = os.path.join(ROOT, "pushworld_amd", "data", "puzzles", "level1")
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".pwp")]
+
+
+def cpu_baseline(paths, ids_full, max_steps, pad_h, pad_w, ppc, bw, target_seconds=12.0):
+    """The oracle's C port on the host cores, same puzzle mix / action distribution / render
+    settings, bounded sample (about 10-20 s of CPU work)."""
+    from oracle import c_oracle
+
+    puzzles = []
+    for p in paths:
+        with open(p) as f:
+            puzzles.append(c_oracle.COraclePuzzle(f.read()))
+    B = 4096
+    stride = len(ids_full) // B
+    ids = np.asarray(ids_full[::stride][:B], dtype=np.int32)
+    rng = np.random.default_rng(12345)
+    T = 16
+    acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
+    c_oracle.rollout(puzzles, ids, acts, max_steps, True, pad_h, pad_w, ppc, bw)  # warm (threads, caches)
+    t0 = time.perf_counter()
+    _, threads = c_oracle.rollout(puzzles, ids, acts, max_steps, True, pad_h, pad_w, ppc, bw)
+    dt = time.perf_counter() - t0
+    rate = B * T / dt
+    T2 = int(max(8, min(4096, target_seconds * rate / B)))
+    acts = rng.integers(0, 4, size=(T2, B), dtype=np.uint8)
+    t0 = time.perf_counter()
+    c_oracle.rollout(puzzles, ids, acts, max_steps, True, pad_h, pad_w, ppc, bw)
+    dt = time.perf_counter() - t0
+    return {
+        "value": B * T2 / dt,
+        "unit": "env-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{B} envs (same Level-1 mix) x {T2} steps, step + padded uint8 render ppc={ppc}, "
+                  f"OpenMP over envs, {dt:.1f} s",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--ppc", type=int, default=3)
+    ap.add_argument("--bw", type=int, default=1)
+    ap.add_argument("--obs", choices=["uint8", "float32", "none"], default="uint8")
+    ap.add_argument("--max-steps", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL over xGMI; used only for the timing barrier/reduction
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from pushworld_amd import _capi
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = level1_paths()
+    B = args.envs_per_gpu
+    K, Wm = args.steps, args.warmup
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B  # grouped by puzzle, ~964 envs each
+    obs_mode = None if args.obs == "none" else args.obs
+    vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=args.max_steps,
+                       border_width=args.bw, pixels_per_cell=args.ppc, observation=obs_mode,
+                       device=local_rank, autoreset=True)
+    eng = vec.engine
+    dev = vec.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    actions = torch.randint(0, 4, (K + Wm, B), generator=gen, device=dev, dtype=torch.uint8)
+
+    vec.reset()
+
+    def one_step(t, events=None):
+        a = actions[t]
+        if obs_mode is None:
+            eng.step(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
+                     vec.flags)
+            return
+        eng.step(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
+                 vec.flags)
+        if events is not None:
+            events[0].record()
+        eng.render(vec.puzzle_id, vec.pos, vec._obs_storage)
+        if events is not None:
+            events[1].record()
+
+    for t in range(Wm):
+        one_step(t)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    episodes = torch.zeros((), dtype=torch.int64, device=dev)
+
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(K):
+        one_step(Wm + t, evs[t] if obs_mode is not None else None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([B * K], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_steps = int(cnt.item())
+
+    if rank == 0:
+        n_obj = eng.np
+        state_bytes = 2 * n_obj * 2 + 1 + 4 + 4 * 2 + 8 + 1 + 1 + 1  # pos r/w, action, pid, steps r/w, reward, flags
+        out = {
+            "metric": "env-steps/sec",
+            "value": total_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": 1000.0 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8" if args.obs != "float32" else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3: Level-1 mix (68 puzzles, envs grouped by puzzle), step + RGB render every step",
+                "envs_per_gpu": B,
+                "global_batch": B * world,
+                "frame_cells": [eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc],
+                "pixels_per_cell": args.ppc,
+                "border_width": args.bw,
+                "observation": args.obs,
+                "obs_shape": list(eng.obs_shape),
+                "max_steps": args.max_steps,
+                "autoreset": "next-step",
+                "n_pad": n_obj,
+                "parallelism": f"env-sharded x{world}, no data-path collective",
+            },
+        }
+        if obs_mode is not None:
+            ms = np.array([a.elapsed_time(b) for a, b in evs])
+            render_s = float(ms.mean()) * 1e-3
+            algo = B * (eng.obs_bytes + 2 * n_obj + 4)  # obs write + pos read + puzzle id read
+            achieved = algo / render_s / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_render_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    with open(pmc) as f:
+                        rec = json.load(f)
+                    if rec.get("envs") == B and rec.get("obs_bytes") == eng.obs_bytes:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                except Exception:  # noqa: BLE001
+                    traffic = None
+            out["roofline"] = {
+                "kernel": "pw_render_u8_ppc3_kernel" if (args.obs == "uint8" and args.ppc == 3 and args.bw == 1)
+                else "pw_render_generic_kernel",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_copy_6290": achieved / 6290.0,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo,
+                "avg_launch_ms": float(ms.mean()),
+                "min_launch_ms": float(ms.min()),
+                "step_kernel_share_ms": 1000.0 * elapsed / K - float(ms.mean()),
+            }
+            out["config"]["algorithmic_bytes_per_env_step"] = eng.obs_bytes + state_bytes
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(paths, ids, args.max_steps, eng.obs_shape[0] // args.ppc,
+                                                   eng.obs_shape[1] // args.ppc, args.ppc, args.bw)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

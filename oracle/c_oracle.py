@@ -1,0 +1,145 @@
+"""ctypes front-end of ``oracle/pw_oracle.c``  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+The C file is the compiled restatement of the reference algorithm (tables + LIFO frontier +
+painter) used as a fast checker in tests and as the ``cpu_baseline`` ("port") of bench.py.
+Parsing comes from ``oracle/pw_oracle.py``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_double, c_int, c_int32, c_uint8, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+from . import pw_oracle
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libpw_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "pw_oracle.c")
+        if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+            subprocess.run(["make", "-s", "-C", _HERE], check=True)
+        l = ctypes.CDLL(_LIB)
+        ip = POINTER(c_int)
+        l.or_puzzle_create.restype = c_void_p
+        l.or_puzzle_create.argtypes = [c_int, c_int, c_int, c_int, c_int, ip, ip, ip, ip, ip, ip, c_int, ip, c_int, ip]
+        l.or_puzzle_destroy.argtypes = [c_void_p]
+        l.or_static_size.argtypes = [c_void_p, c_int, c_int]
+        l.or_dynamic_size.argtypes = [c_void_p, c_int, c_int, c_int]
+        l.or_step.restype = c_uint32
+        l.or_step.argtypes = [c_void_p, ip, c_int]
+        l.or_count_goals.argtypes = [c_void_p, ip]
+        l.or_env_step.argtypes = [c_void_p, ip, c_int, POINTER(c_double)]
+        l.or_render.argtypes = [c_void_p, ip, c_int, c_int, c_void_p]
+        l.or_observation_u8.argtypes = [c_void_p, ip, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+        l.or_observation_f32.argtypes = [c_void_p, ip, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+        l.or_rollout.restype = c_uint64
+        l.or_rollout.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_int, c_int, POINTER(c_uint8), c_int, c_int,
+                                 c_int, c_int, c_int, c_int, POINTER(c_int)]
+        _lib = l
+    return _lib
+
+
+def _ints(seq):
+    arr = np.ascontiguousarray(np.asarray(list(seq), dtype=np.int32).reshape(-1))
+    if arr.size == 0:
+        arr = np.zeros((2,), np.int32)
+    return arr, arr.ctypes.data_as(POINTER(c_int))
+
+
+class COraclePuzzle:
+    def __init__(self, text: str, order: str = "python"):
+        self.py = pw_oracle.OraclePuzzle(text, order=order, build_tables=False)
+        p = self.py
+        flat = lambda cells: [v for c in sorted(cells) for v in c]  # noqa: E731
+        keep = []
+
+        def arr(seq):
+            a, ptr = _ints(seq)
+            keep.append(a)
+            return ptr
+
+        self.handle = lib().or_puzzle_create(
+            p.width, p.height, p.num_movables, p.num_goals, int(p.has_agent_walls),
+            arr([len(s) for s in p.shapes]), arr([v for s in p.shapes for v in flat(s)]),
+            arr([v for xy in p.initial_state for v in xy]), arr([v for xy in p.goal_state for v in xy]),
+            arr([len(s) for s in p.goal_shapes]), arr([v for s in p.goal_shapes for v in flat(s)]),
+            len(p.wall_cells), arr(flat(p.wall_cells)),
+            len(p.agent_wall_cells), arr(flat(p.agent_wall_cells)),
+        )
+        assert self.handle, "or_puzzle_create failed"
+        self.width, self.height = p.width, p.height
+        self.num_movables, self.num_goals = p.num_movables, p.num_goals
+        self.initial_state = p.initial_state
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.or_puzzle_destroy(self.handle)
+            self.handle = None
+
+    def _state(self, state):
+        a = np.ascontiguousarray(np.asarray(state, dtype=np.int32).reshape(-1))
+        return a, a.ctypes.data_as(POINTER(c_int))
+
+    def get_next_state_moved(self, state, action):
+        a, ptr = self._state(state)
+        mask = lib().or_step(self.handle, ptr, int(action))
+        nxt = tuple((int(a[2 * k]), int(a[2 * k + 1])) for k in range(self.num_movables))
+        return nxt, [k for k in range(self.num_movables) if (mask >> k) & 1]
+
+    def get_next_state(self, state, action):
+        return self.get_next_state_moved(state, action)[0]
+
+    def env_step(self, state, action):
+        a, ptr = self._state(state)
+        r = c_double()
+        term = lib().or_env_step(self.handle, ptr, int(action), ctypes.byref(r))
+        nxt = tuple((int(a[2 * k]), int(a[2 * k + 1])) for k in range(self.num_movables))
+        return nxt, r.value, bool(term)
+
+    def table_sizes(self):
+        n = self.num_movables
+        s = np.array([[lib().or_static_size(self.handle, a, i) for i in range(n)] for a in range(4)])
+        d = np.array([[[lib().or_dynamic_size(self.handle, a, i, j) for j in range(n)] for i in range(n)]
+                      for a in range(4)])
+        return s, d
+
+    def render(self, state, border_width=2, pixels_per_cell=20):
+        _, ptr = self._state(state)
+        img = np.zeros((self.height * pixels_per_cell, self.width * pixels_per_cell, 3), np.uint8)
+        lib().or_render(self.handle, ptr, pixels_per_cell, border_width, img.ctypes.data)
+        return img
+
+    def observation(self, state, max_cell_height, max_cell_width, pixels_per_cell=20, border_width=2, dtype="f32"):
+        _, ptr = self._state(state)
+        ppc = pixels_per_cell
+        scratch = np.zeros((self.height * ppc * self.width * ppc * 3,), np.uint8)
+        if dtype == "f32":
+            out = np.zeros((max_cell_height * ppc, max_cell_width * ppc, 3), np.float32)
+            lib().or_observation_f32(self.handle, ptr, max_cell_height, max_cell_width, ppc, border_width,
+                                     out.ctypes.data, scratch.ctypes.data)
+        else:
+            out = np.zeros((max_cell_height * ppc, max_cell_width * ppc, 3), np.uint8)
+            lib().or_observation_u8(self.handle, ptr, max_cell_height, max_cell_width, ppc, border_width,
+                                    out.ctypes.data, scratch.ctypes.data)
+        return out
+
+
+def rollout(puzzles, puzzle_ids, actions, max_steps, render, pad_h, pad_w, ppc, bw):
+    """Batched CPU baseline: ``actions`` uint8 [T][B].  Returns (checksum, threads used)."""
+    handles = (c_void_p * len(puzzles))(*[p.handle for p in puzzles])
+    pid = np.ascontiguousarray(np.asarray(puzzle_ids, dtype=np.int32))
+    acts = np.ascontiguousarray(np.asarray(actions, dtype=np.uint8))
+    T, B = acts.shape
+    used = c_int(0)
+    chk = lib().or_rollout(handles, pid.ctypes.data_as(POINTER(c_int32)), B, T,
+                           acts.ctypes.data_as(POINTER(c_uint8)), int(max_steps or 0), int(bool(render)),
+                           pad_h, pad_w, ppc, bw, ctypes.byref(used))
+    return int(chk), used.value

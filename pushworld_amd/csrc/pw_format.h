@@ -59,19 +59,24 @@ struct PwObjEntry {      // 4 bytes per movable
   uint16_t row_off;      // index of the first shape row (uint64 units) in the shape section
 };
 
-struct PwPuzzleHeader {  // 48 bytes
+// Fixed 320-byte record per puzzle.  Everything a step needs besides the row bitboards
+// (object table, goal and initial positions) sits inside the record so that a wavefront
+// fetches it with ONE level of indirection (wave-uniform scalar loads); the bitboards and the
+// render tables live in the blob at `base`.
+struct PwPuzzleHeader {
   uint32_t base;         // byte offset of this puzzle's data in the blob (8 B aligned)
   uint8_t W, H, N, G;    // grid size incl. border walls, #movables (agent first), #goals
   uint32_t off_wall;     // uint64[H]  wall rows                     (offsets relative to base)
   uint32_t off_awall;    // uint64[H]  wall | agent-wall rows
-  uint32_t off_objtab;   // PwObjEntry[N]
   uint32_t off_shapes;   // uint64[sum h_j]  object shape rows, bit x = cell (x, row)
-  uint32_t off_init;     // int8[N][2] initial positions
-  uint32_t off_goal;     // int8[G][2] goal positions (goal k belongs to movable k+1)
   uint32_t off_static;   // uint32[H*W] static cell codes (walls, agent walls, goal masks)
   uint32_t off_mcells;   // uint32[n_mcells]: cx | cy<<8 | absent mask<<16 | object<<24
   uint32_t n_mcells;
   uint32_t has_aw;
+  uint32_t reserved[7];
+  PwObjEntry objtab[32];  // @64   bounding boxes + shape row offsets
+  int8_t goal[32][2];     // @192  goal k is the target of movable k+1
+  int8_t init[32][2];     // @256  initial positions
 };
 
 #endif  // PW_FORMAT_H_

@@ -215,7 +215,6 @@ void pack_puzzle(const PwPuzzle& pz, PwPuzzleHeader* hdr, std::vector<uint8_t>& 
   hdr->off_wall = append(blob, wall_rows) - base;
   hdr->off_awall = append(blob, awall_rows) - base;
 
-  std::vector<PwObjEntry> objtab(N);
   std::vector<uint64_t> shape_rows;
   for (int j = 0; j < N; j++) {
     int w = 0, h = 0;
@@ -223,27 +222,22 @@ void pack_puzzle(const PwPuzzle& pz, PwPuzzleHeader* hdr, std::vector<uint8_t>& 
       w = std::max(w, c.first + 1);
       h = std::max(h, c.second + 1);
     }
-    objtab[j].w = static_cast<uint8_t>(w);
-    objtab[j].h = static_cast<uint8_t>(h);
-    objtab[j].row_off = static_cast<uint16_t>(shape_rows.size());
+    hdr->objtab[j].w = static_cast<uint8_t>(w);
+    hdr->objtab[j].h = static_cast<uint8_t>(h);
+    hdr->objtab[j].row_off = static_cast<uint16_t>(shape_rows.size());
     std::vector<uint64_t> rows(h, 0);
     for (const auto& c : pz.shapes[j]) rows[c.second] |= 1ull << c.first;
     shape_rows.insert(shape_rows.end(), rows.begin(), rows.end());
   }
-  hdr->off_objtab = append(blob, objtab) - base;
   hdr->off_shapes = append(blob, shape_rows) - base;
-
-  std::vector<int8_t> init(2 * N), goal(2 * std::max(G, 1), 0);
   for (int j = 0; j < N; j++) {
-    init[2 * j] = static_cast<int8_t>(pz.initial[j].first);
-    init[2 * j + 1] = static_cast<int8_t>(pz.initial[j].second);
+    hdr->init[j][0] = static_cast<int8_t>(pz.initial[j].first);
+    hdr->init[j][1] = static_cast<int8_t>(pz.initial[j].second);
   }
   for (int g = 0; g < G; g++) {
-    goal[2 * g] = static_cast<int8_t>(pz.goal[g].first);
-    goal[2 * g + 1] = static_cast<int8_t>(pz.goal[g].second);
+    hdr->goal[g][0] = static_cast<int8_t>(pz.goal[g].first);
+    hdr->goal[g][1] = static_cast<int8_t>(pz.goal[g].second);
   }
-  hdr->off_init = append(blob, init) - base;
-  hdr->off_goal = append(blob, goal) - base;
 
   // static render codes: painter's order AW(uW) -> W, goal outlines kept separately in
   // the top byte (puzzle.py:453-458).

@@ -58,62 +58,88 @@ __device__ __forceinline__ uint64_t shift_rows(uint64_t r, int act, int lane) {
 }
 
 struct PuzzleView {
+  const PwPuzzleHeader* h;  // wave-uniform: fields are fetched with scalar loads
   const uint64_t* wall;
   const uint64_t* awall;
-  const PwObjEntry* objtab;
   const uint64_t* shapes;
-  const int8_t* init;
-  const int8_t* goal;
   const uint32_t* stat;
   const uint32_t* mcells;
   int W, H, N, G, n_mcells;
 };
 
 __device__ __forceinline__ PuzzleView view_of(const PwPuzzleHeader* hdrs, const uint8_t* blob, int pid) {
-  const PwPuzzleHeader& h = hdrs[pid];
-  const uint8_t* b = blob + h.base;
+  const PwPuzzleHeader* h = hdrs + pid;
+  const uint8_t* b = blob + h->base;
   PuzzleView v;
-  v.wall = reinterpret_cast<const uint64_t*>(b + h.off_wall);
-  v.awall = reinterpret_cast<const uint64_t*>(b + h.off_awall);
-  v.objtab = reinterpret_cast<const PwObjEntry*>(b + h.off_objtab);
-  v.shapes = reinterpret_cast<const uint64_t*>(b + h.off_shapes);
-  v.init = reinterpret_cast<const int8_t*>(b + h.off_init);
-  v.goal = reinterpret_cast<const int8_t*>(b + h.off_goal);
-  v.stat = reinterpret_cast<const uint32_t*>(b + h.off_static);
-  v.mcells = reinterpret_cast<const uint32_t*>(b + h.off_mcells);
-  v.W = h.W;
-  v.H = h.H;
-  v.N = h.N;
-  v.G = h.G;
-  v.n_mcells = static_cast<int>(h.n_mcells);
+  v.h = h;
+  v.wall = reinterpret_cast<const uint64_t*>(b + h->off_wall);
+  v.awall = reinterpret_cast<const uint64_t*>(b + h->off_awall);
+  v.shapes = reinterpret_cast<const uint64_t*>(b + h->off_shapes);
+  v.stat = reinterpret_cast<const uint32_t*>(b + h->off_static);
+  v.mcells = reinterpret_cast<const uint32_t*>(b + h->off_mcells);
+  v.W = h->W;
+  v.H = h->H;
+  v.N = h->N;
+  v.G = h->G;
+  v.n_mcells = static_cast<int>(h->n_mcells);
   return v;
 }
 
-// lane r's row of object j placed at (x, y)
-__device__ __forceinline__ uint64_t object_row(const PuzzleView& pv, int j, int x, int y, int lane) {
-  const PwObjEntry e = pv.objtab[j];
+// lane r's row of object j placed at the packed position p = x | y << 8 (int8 each)
+__device__ __forceinline__ uint64_t object_row(const PuzzleView& pv, int j, int p, int lane) {
+  const PwObjEntry e = pv.h->objtab[j];
+  const int x = static_cast<int8_t>(p & 0xff), y = static_cast<int8_t>((p >> 8) & 0xff);
   const int rr = lane - y;
   uint64_t r = 0;
   if (static_cast<unsigned>(rr) < static_cast<unsigned>(e.h)) r = pv.shapes[e.row_off + rr];
   return (static_cast<unsigned>(x) < 64u) ? (r << x) : 0ull;
 }
 
+// What one wavefront keeps of an environment: the agent's row bitboard, the union of all
+// other movables, and whether the state is overlap-free.  Individual object rows are only
+// re-read (L1/L2 hits) in the ~1 % of steps in which the agent actually touches something.
+struct EnvBoards {
+  uint64_t agent;   // lane r = row r of the agent
+  uint64_t others;  // union of movables 1..N-1
+  uint64_t wall, awall;
+  bool legal;       // no movable/movable overlap, no non-agent movable on a wall
+};
+
+__device__ __forceinline__ EnvBoards load_boards(const PuzzleView& pv, int xy, int lane) {
+  EnvBoards b;
+  b.wall = 0;
+  b.awall = 0;
+  if (lane < pv.H) {
+    b.wall = pv.wall[lane];
+    b.awall = pv.awall[lane];
+  }
+  b.agent = object_row(pv, 0, __builtin_amdgcn_readlane(xy, 0), lane);
+  uint64_t acc = b.agent, overlap = 0, others = 0;
+  for (int j = 1; j < pv.N; j++) {
+    const uint64_t rj = object_row(pv, j, __builtin_amdgcn_readlane(xy, j), lane);
+    overlap |= acc & rj;
+    acc |= rj;
+    others |= rj;
+  }
+  overlap |= others & b.wall;
+  b.others = others;
+  b.legal = !wave_any(overlap != 0);
+  return b;
+}
+
 // Exact pairwise closure for states in which objects already overlap each other or a wall
 // (never produced by legal play; pins the "not already overlapping" clause,
-// puzzle.py:562,592).  Rows are re-read with dynamic indices to keep the code small.
-__device__ __noinline__ uint32_t closure_pairwise(const PuzzleView& pv, int xy_packed, int act, int lane,
-                                                  uint64_t wall) {
+// puzzle.py:562,592).
+__device__ __forceinline__ uint32_t closure_pairwise(const PuzzleView& pv, int xy, int act, int lane, uint64_t wall) {
   uint32_t pushed = 1u, frontier = 1u;
   while (frontier) {
     const int i = __ffs(frontier) - 1;
     frontier &= ~(1u << i);
-    const int pi = __builtin_amdgcn_readlane(xy_packed, i);
-    const uint64_t ri = object_row(pv, i, static_cast<int8_t>(pi & 0xff), static_cast<int8_t>((pi >> 8) & 0xff), lane);
+    const uint64_t ri = object_row(pv, i, __builtin_amdgcn_readlane(xy, i), lane);
     const uint64_t si = shift_rows(ri, act, lane);
     for (int j = 1; j < pv.N; j++) {
       if ((pushed >> j) & 1u) continue;
-      const int pj = __builtin_amdgcn_readlane(xy_packed, j);
-      const uint64_t rj = object_row(pv, j, static_cast<int8_t>(pj & 0xff), static_cast<int8_t>((pj >> 8) & 0xff), lane);
+      const uint64_t rj = object_row(pv, j, __builtin_amdgcn_readlane(xy, j), lane);
       if (wave_any((si & rj) != 0) && !wave_any((ri & rj) != 0)) {
         const uint64_t sj = shift_rows(rj, act, lane);
         if (wave_any((sj & wall) != 0) && !wave_any((rj & wall) != 0)) return 0u;  // transitive stopping
@@ -125,48 +151,36 @@ __device__ __noinline__ uint32_t closure_pairwise(const PuzzleView& pv, int xy_p
   return pushed;
 }
 
-// Push-set fixed point for one environment held by one wavefront.
-//   row[j]     lane r = row r of object j at its current position (0 for j >= N)
-//   xy_packed  lane j = (x | y << 8) of object j (for the slow path)
+// Push-set fixed point for one environment held by one wavefront (puzzle.py:348-382).
+//   xy  lane j = (x | y << 8) of object j
 // Returns the bit mask of objects that move (bit 0 = agent), 0 when nothing moves.
-template <int NP>
-__device__ __forceinline__ uint32_t push_closure(const PuzzleView& pv, const uint64_t (&row)[NP], uint64_t wall,
-                                                 uint64_t awall, int xy_packed, int act, int lane) {
+__device__ __forceinline__ uint32_t push_closure(const PuzzleView& pv, const EnvBoards& b, int xy, int act,
+                                                 int lane) {
   // agent vs walls + agent walls (puzzle.py:353; static table of the agent, :272-281)
-  const uint64_t s0 = shift_rows(row[0], act, lane);
-  if (wave_any((s0 & awall) != 0) && !wave_any((row[0] & awall) != 0)) return 0u;
-
-  // Is the state free of overlaps (movable/movable and non-agent movable/wall)?  Always true
-  // for states reached by legal play; then the pairwise rule collapses to tests against the
-  // union of the displaced push set.
-  uint64_t acc = row[0], overlap = 0, others = 0;
-#pragma unroll
-  for (int j = 1; j < NP; j++) {
-    overlap |= acc & row[j];
-    acc |= row[j];
-    others |= row[j];
-  }
-  overlap |= others & wall;
-  if (wave_any(overlap != 0)) return closure_pairwise(pv, xy_packed, act, lane, wall);
-
-  if (!wave_any((s0 & others) != 0)) return 1u;  // ~79 % of steps: the agent moves alone
+  const uint64_t s0 = shift_rows(b.agent, act, lane);
+  if (wave_any((s0 & b.awall) != 0) && !wave_any((b.agent & b.awall) != 0)) return 0u;
+  // States reached by legal play never contain overlaps; then the pairwise rule collapses to
+  // tests against the union of the displaced push set.
+  if (!b.legal) return closure_pairwise(pv, xy, act, lane, b.wall);
+  if (!wave_any((s0 & b.others) != 0)) return 1u;  // ~79 % of steps: the agent moves alone
 
   uint32_t pushed = 1u;
   uint64_t front = s0;  // displaced rows of the objects added in the previous sweep
   for (;;) {
     uint32_t fresh = 0u;
     uint64_t add = 0;
-#pragma unroll
-    for (int j = 1; j < NP; j++) {
-      if (j < pv.N && !((pushed >> j) & 1u) && wave_any((front & row[j]) != 0)) {
+    for (int j = 1; j < pv.N; j++) {
+      if ((pushed >> j) & 1u) continue;
+      const uint64_t rj = object_row(pv, j, __builtin_amdgcn_readlane(xy, j), lane);
+      if (wave_any((front & rj) != 0)) {
         fresh |= 1u << j;
-        add |= row[j];
+        add |= rj;
       }
     }
     if (!fresh) break;
     pushed |= fresh;
     front = shift_rows(add, act, lane);
-    if (wave_any((front & wall) != 0)) return 0u;  // a pushed object hits a wall: nothing moves
+    if (wave_any((front & b.wall) != 0)) return 0u;  // a pushed object hits a wall: nothing moves
   }
   return pushed;
 }
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(256) void pw_reset_kernel(ResetArgs a) {
   if (a.mask && !a.mask[env]) return;
   const PwPuzzleHeader& h = a.hdrs[a.puzzle_id[env]];
   int16_t v = 0;
-  if (j < h.N) v = reinterpret_cast<const int16_t*>(a.blob + h.base + h.off_init)[j];
+  if (j < h.N) v = reinterpret_cast<const int16_t*>(h.init)[j];
   reinterpret_cast<int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + j] = v;
   if (j == 0) {
     a.steps[env] = 0;
@@ -222,23 +236,30 @@ struct StepArgs {
   int32_t batch;
   int32_t max_steps;
   uint32_t flags;
+  int32_t np;
 };
 
-template <int NP>
 __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
   const int lane = threadIdx.x & (PW_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int env = blockIdx.x * (256 / PW_WAVE) + wave;
   if (env >= a.batch) return;
+  const int NP = a.np;
 
+  // first-level loads, all independent
   const int pid = __builtin_amdgcn_readfirstlane(a.puzzle_id[env]);
-  const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
   const int act = __builtin_amdgcn_readfirstlane(static_cast<int>(a.actions[env]));
+  const int was_done = __builtin_amdgcn_readfirstlane(static_cast<int>(a.term[env] | a.trunc[env]));
+  const int steps_in = __builtin_amdgcn_readfirstlane(a.steps[env]);
   int16_t* prow = reinterpret_cast<int16_t*>(a.pos) + static_cast<int64_t>(env) * NP;
+  int xy = 0;  // coalesced load of the packed (x, y) int8 pairs: lane j holds object j
+  if (lane < NP) xy = static_cast<uint16_t>(prow[lane]);
 
-  if ((a.flags & PW_STEP_AUTORESET) && (a.term[env] | a.trunc[env])) {
+  const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
+
+  if ((a.flags & PW_STEP_AUTORESET) && was_done) {
     // next-step autoreset: this call is the reset() of a finished episode
-    if (lane < NP) prow[lane] = lane < pv.N ? reinterpret_cast<const int16_t*>(pv.init)[lane] : int16_t(0);
+    if (lane < NP) prow[lane] = lane < pv.N ? reinterpret_cast<const int16_t*>(pv.h->init)[lane] : int16_t(0);
     if (lane == 0) {
       a.steps[env] = 0;
       a.term[env] = 0;
@@ -256,26 +277,8 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
     return;
   }
 
-  // coalesced load of the packed (x, y) int8 pairs: lane j holds object j
-  int xy = 0;
-  if (lane < NP) xy = static_cast<uint16_t>(prow[lane]);
-
-  uint64_t wall = 0, awall = 0;
-  if (lane < pv.H) {
-    wall = pv.wall[lane];
-    awall = pv.awall[lane];
-  }
-  uint64_t row[NP];
-#pragma unroll
-  for (int j = 0; j < NP; j++) {
-    row[j] = 0;
-    if (j < pv.N) {
-      const int pj = __builtin_amdgcn_readlane(xy, j);
-      row[j] = object_row(pv, j, static_cast<int8_t>(pj & 0xff), static_cast<int8_t>((pj >> 8) & 0xff), lane);
-    }
-  }
-
-  const uint32_t pushed = push_closure<NP>(pv, row, wall, awall, xy, act, lane);
+  const EnvBoards b = load_boards(pv, xy, lane);
+  const uint32_t pushed = push_closure(pv, b, xy, act, lane);
 
   // displaced state (puzzle.py:384-394) + goal bookkeeping (puzzle.py:396-411)
   const int dx = act == 0 ? -1 : (act == 1 ? 1 : 0);
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
   int x = static_cast<int8_t>(xy & 0xff), y = static_cast<int8_t>((xy >> 8) & 0xff);
   const bool is_goal_lane = lane >= 1 && lane <= pv.G;
   int gxy = 0;
-  if (is_goal_lane) gxy = reinterpret_cast<const uint16_t*>(pv.goal)[lane - 1];
+  if (is_goal_lane) gxy = reinterpret_cast<const uint16_t*>(pv.h->goal)[lane - 1];
   const int before = __popcll(__ballot(is_goal_lane && (xy & 0xffff) == gxy));
   if ((pushed >> lane) & 1u) {
     x += dx;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
 
   if (lane == 0) {
     const bool terminated = after == pv.G;  // vacuously true without goals (trap T8)
-    const int s = a.steps[env] + 1;
+    const int s = steps_in + 1;
     a.steps[env] = s;
     a.term[env] = terminated ? 1 : 0;
     a.trunc[env] = (a.max_steps > 0 && s >= a.max_steps) ? 1 : 0;
@@ -319,7 +322,6 @@ struct ExpandArgs {
   int32_t num_states;
 };
 
-template <int NP>
 __global__ __launch_bounds__(256) void pw_expand4_kernel(ExpandArgs a) {
   const int lane = threadIdx.x & (PW_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -336,30 +338,17 @@ __global__ __launch_bounds__(256) void pw_expand4_kernel(ExpandArgs a) {
     y = p2d - x * PW_POSITION_LIMIT;
   }
   const int xy = (x & 0xff) | ((y & 0xff) << 8);
+  const EnvBoards b = load_boards(pv, xy, lane);
 
-  uint64_t wall = 0, awall = 0;
-  if (lane < pv.H) {
-    wall = pv.wall[lane];
-    awall = pv.awall[lane];
-  }
-  uint64_t row[NP];
-#pragma unroll
-  for (int j = 0; j < NP; j++) {
-    row[j] = 0;
-    if (j < N) {
-      const int pj = __builtin_amdgcn_readlane(xy, j);
-      row[j] = object_row(pv, j, static_cast<int8_t>(pj & 0xff), static_cast<int8_t>((pj >> 8) & 0xff), lane);
-    }
-  }
   const bool is_goal_lane = lane >= 1 && lane <= pv.G;
   int g2d = 0;
   if (is_goal_lane) {
-    const int gxy = reinterpret_cast<const uint16_t*>(pv.goal)[lane - 1];
+    const int gxy = reinterpret_cast<const uint16_t*>(pv.h->goal)[lane - 1];
     g2d = (gxy & 0xff) * PW_POSITION_LIMIT + ((gxy >> 8) & 0xff);
   }
 
   for (int act = 0; act < 4; act++) {
-    const uint32_t pushed = push_closure<NP>(pv, row, wall, awall, xy, act, lane);
+    const uint32_t pushed = push_closure(pv, b, xy, act, lane);
     const int disp = act == 0 ? -PW_POSITION_LIMIT : (act == 1 ? PW_POSITION_LIMIT : (act == 2 ? -1 : 1));
     const int n2d = p2d + (((pushed >> lane) & 1u) ? disp : 0);
     const int64_t o = static_cast<int64_t>(sidx) * 4 + act;
@@ -796,15 +785,9 @@ int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_
     return pw_fail(PW_EINVAL, "null argument");
   if (batch <= 0) return PW_OK;
   StepArgs a{e->set->d_headers, e->set->d_blob, puzzle_id, actions, pos, steps, reward, dgoals,
-             terminated, truncated, batch, e->cfg.max_steps, flags};
+             terminated, truncated, batch, e->cfg.max_steps, flags, e->np};
   const unsigned blocks = static_cast<unsigned>((batch + 3) / 4);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (e->np) {
-    case 4: hipLaunchKernelGGL(pw_step_kernel<4>, dim3(blocks), dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(pw_step_kernel<8>, dim3(blocks), dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(pw_step_kernel<16>, dim3(blocks), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(pw_step_kernel<32>, dim3(blocks), dim3(256), 0, st, a); break;
-  }
+  hipLaunchKernelGGL(pw_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("pw_step");
 }
 
@@ -841,13 +824,7 @@ int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ
   if (num_states <= 0) return PW_OK;
   ExpandArgs a{e->set->d_headers, e->set->d_blob, puzzle, states, succ, moved, goal, num_states};
   const unsigned blocks = static_cast<unsigned>((num_states + 3) / 4);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (e->np) {
-    case 4: hipLaunchKernelGGL(pw_expand4_kernel<4>, dim3(blocks), dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(pw_expand4_kernel<8>, dim3(blocks), dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(pw_expand4_kernel<16>, dim3(blocks), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(pw_expand4_kernel<32>, dim3(blocks), dim3(256), 0, st, a); break;
-  }
+  hipLaunchKernelGGL(pw_expand4_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("pw_expand4");
 }
 

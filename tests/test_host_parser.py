@@ -1,0 +1,190 @@
+"""Host library (C++ parser / packer behind the C ABI) against the golden parse products,
+the reference's error behaviour, and -- through the packed bitboards -- the reference's
+collision tables.  CPU only: no kernel is launched."""
+import ctypes
+import hashlib
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from pushworld_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def digest_points(points):
+    return sha(np.array(sorted(points), dtype=np.int32).reshape(-1, 2))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/pushworld_amd.h is exported and bound."""
+    with open(os.path.join(ROOT, "include", "pushworld_amd.h")) as f:
+        src = f.read()
+    declared = set(re.findall(r"\b(pw_[a-z0-9_]+)\s*\(", src))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    assert lib.pw_abi_version() == 1
+
+
+def test_parse_products_match_reference(golden):
+    """Python object order: dimensions, states, cells, walls for all 700 golden puzzles."""
+    for k in golden.keys:
+        m = golden.meta[k]
+        p = _capi.ParsedPuzzle(golden.text(k), _capi.ORDER_PYTHON)
+        assert (p.width, p.height, p.num_movables) == (m["width"], m["height"], m["num_movables"]), k
+        assert [list(x) for x in p.initial_state] == m["initial_state"], k
+        assert [list(x) for x in p.goal_state] == m["goal_state"], k
+        assert [sorted(map(list, c)) for c in p.object_cells] == m["object_cells"], k
+        assert [sorted(map(list, c)) for c in p.goal_cells] == m["goal_cells"], k
+        assert digest_points(p.wall_cells) == m["walls_sha"], k
+        assert digest_points(set(p.agent_wall_cells) | set(p.wall_cells)) == m["agent_walls_prop_sha"], k
+        assert p.has_agent_walls == m["has_agent_walls"], k
+
+
+def test_cpp_object_order(golden):
+    """cpp/test/test_pushworld_puzzle.cc:467-477 (C++ order) vs python3/test/test_puzzle.py:203-211."""
+    text = golden.text("cpptest:file_parsing.pwp")
+    c = _capi.ParsedPuzzle(text, _capi.ORDER_CPP)
+    assert c.names == ["a", "m1", "m4", "m0", "m2", "m3"]
+    assert c.initial_state == ((1, 12), (1, 3), (6, 14), (4, 1), (2, 7), (3, 8))
+    assert c.goal_state == ((3, 4), (6, 5))
+    p = _capi.ParsedPuzzle(text, _capi.ORDER_PYTHON)
+    assert p.names == ["a", "m4", "m1", "m0", "m2", "m3"]
+    assert p.goal_state == ((6, 5), (3, 4))
+    assert (p.width, p.height) == (12, 18)
+
+
+def test_cpp_order_matches_oracle_everywhere(golden):
+    from oracle import pw_oracle
+
+    for k in [k for k in golden.keys if not k.startswith("l0:")]:
+        text = golden.text(k)
+        c = _capi.ParsedPuzzle(text, _capi.ORDER_CPP)
+        o = pw_oracle.OraclePuzzle(text, order="cpp", build_tables=False)
+        assert c.names == o.names and c.initial_state == o.initial_state and c.goal_state == o.goal_state, k
+
+
+def test_parse_errors():
+    """puzzle.py:141-157, :230-232 / pushworld_puzzle.cc:216,236,292."""
+    with pytest.raises(ValueError, match="same number of elements"):
+        _capi.ParsedPuzzle("a . .\n. .\n")
+    with pytest.raises(ValueError, match="agent"):
+        _capi.ParsedPuzzle(". . .\n. m0 .\n")
+    with pytest.raises(AssertionError, match="m7"):
+        _capi.ParsedPuzzle("a . g7\n. m0 .\n")
+    with pytest.raises(ValueError, match="64"):
+        _capi.ParsedPuzzle(" ".join(["a"] + ["."] * 70) + "\n")
+    big = "\n".join(" ".join(f"m{r * 6 + c}" for c in range(6)) for r in range(6)) + "\na . . . . .\n"
+    with pytest.raises(ValueError, match="32"):
+        _capi.ParsedPuzzle(big)
+    # lower-casing, '+' cells, ragged whitespace
+    p = _capi.ParsedPuzzle("A   G0+M0  .\n  W  aw+m1 .\n")
+    assert p.names == ["a", "m0", "m1"] and p.goal_state == ((2, 1),) and p.has_agent_walls
+
+
+# ------------------------------------------------------------------ packed tables
+HDR = struct.Struct("<I4B10I")  # PwPuzzleHeader, csrc/pw_format.h
+
+
+
+
+def bitboard_tables(parsed):
+    """The reference's collision tables recomputed from the row-bitboard predicate the
+    kernels evaluate: collides <=> shift(mask_i) & mask_j != 0 and mask_i & mask_j == 0."""
+    W, H, n = parsed.width, parsed.height, parsed.num_movables
+    wall = np.zeros((H, W), bool)
+    for x, y in parsed.wall_cells:
+        wall[y, x] = True
+    awall = wall.copy()
+    for x, y in parsed.agent_wall_cells:
+        awall[y, x] = True
+    shapes = []
+    for cells in parsed.object_cells:
+        w = max(c[0] for c in cells) + 1
+        h = max(c[1] for c in cells) + 1
+        m = np.zeros((h, w), bool)
+        for x, y in cells:
+            m[y, x] = True
+        shapes.append(m)
+    disp = [(-1, 0), (1, 0), (0, -1), (0, 1)]
+
+    def place(m, x, y, HH, WW, ox=0, oy=0):
+        """Board of size HH x WW with shape m at (x+ox, y+oy); cells outside are dropped."""
+        b = np.zeros((HH, WW), bool)
+        h, w = m.shape
+        for yy in range(h):
+            for xx in range(w):
+                if m[yy, xx]:
+                    X, Y = x + xx + ox, y + yy + oy
+                    if 0 <= X < WW and 0 <= Y < HH:
+                        b[Y, X] = True
+        return b
+
+    static = [[set() for _ in range(n)] for _ in range(4)]
+    dynamic = [[[set() for _ in range(n)] for _ in range(n)] for _ in range(4)]
+    for a, (dx, dy) in enumerate(disp):
+        for i in range(n):
+            obst = awall if i == 0 else wall
+            h, w = shapes[i].shape
+            for y in range(0, H - h + 1):
+                for x in range(0, W - w + 1):
+                    now = place(shapes[i], x, y, H, W)
+                    nxt = place(shapes[i], x + dx, y + dy, H, W)
+                    if (nxt & obst).any() and not (now & obst).any():
+                        static[a][i].add((x, y))
+            for j in range(1, n):
+                hj, wj = shapes[j].shape
+                S = 2 * (max(h, hj) + max(w, wj)) + 8
+                c = S // 2
+                bj = place(shapes[j], c, c, S, S)
+                for ry in range(-h - 1, hj + 2):
+                    for rx in range(-w - 1, wj + 2):
+                        now = place(shapes[i], c + rx, c + ry, S, S)
+                        nxt = place(shapes[i], c + rx + dx, c + ry + dy, S, S)
+                        if (nxt & bj).any() and not (now & bj).any():
+                            dynamic[a][i][j].add((rx, ry))
+    return static, dynamic
+
+
+def test_bitboard_predicate_reproduces_reference_tables(golden):
+    """The formulation the kernels use is table-for-table identical to the reference's
+    collision sets (sizes and SHA-256 of sorted contents) on small and medium puzzles."""
+    keys = [k for k in golden.keys if k.startswith(("pytest:", "cpptest:"))]
+    keys += [k for k in golden.keys if k.startswith("l0:")][::40]
+    keys += ["bench:level1/2 Obstacle.pwp", "bench:level1/Choose Wisely.pwp"]
+    for k in keys:
+        m = golden.meta[k]
+        if m["width"] * m["height"] > 400:
+            continue
+        p = _capi.ParsedPuzzle(golden.text(k), _capi.ORDER_PYTHON)
+        static, dynamic = bitboard_tables(p)
+        n = p.num_movables
+        h = hashlib.sha256()
+        for a in range(4):
+            for i in range(n):
+                assert len(static[a][i]) == m["static_sizes"][a][i], (k, a, i)
+                h.update(np.array(sorted(static[a][i]), np.int32).tobytes())
+                for j in range(n):
+                    assert len(dynamic[a][i][j]) == m["dynamic_sizes"][a][i][j], (k, a, i, j)
+                    h.update(np.array(sorted(dynamic[a][i][j]), np.int32).tobytes())
+        assert h.hexdigest() == m["tables_sha"], k
+
+
+def test_puzzleset_host_packing(golden):
+    """Host-only packing (device < 0) works without a GPU; engines cannot be created on it."""
+    ps = [_capi.ParsedPuzzle(golden.text(k)) for k in golden.keys[:40]]
+    s = _capi.PuzzleSet(ps, -1)
+    assert len(s) == 40 and len(s.blob()) % 16 == 0 and len(s.blob()) > 40 * 64
+    assert s.max_width == max(p.width for p in ps) and s.max_movables == max(p.num_movables for p in ps)
+    with pytest.raises(RuntimeError, match="no device tables"):
+        _capi.Engine(s, None, 3, 1, _capi.OBS_U8)
