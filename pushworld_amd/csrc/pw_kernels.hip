@@ -472,7 +472,7 @@ __device__ __forceinline__ void carve_lds(const RenderArgs& a, unsigned char* sm
   pal = grid + a.grid_cap;
   spos = reinterpret_cast<int16_t*>(pal + 16);
   gmask = reinterpret_cast<uint8_t*>(spos + 32);
-  E = reinterpret_cast<uint16_t*>(gmask + ((a.grid_cap + 15) & ~15));
+  E = reinterpret_cast<uint16_t*>(gmask + ((a.grid_cap + 15) & ~15)) + 4;  // 4 guard entries in front
 }
 
 // Fast path: uint8 observation, pixels_per_cell = 3, border_width = 1 (zones == pixels).
@@ -498,9 +498,14 @@ __global__ __launch_bounds__(256) void pw_render_u8_ppc3_kernel(RenderArgs a) {
   const int pady = (a.pad_h - pv.H) * 3 / 2;
   const int padx = (a.pad_w - pv.W) * 3 / 2;
   const int c0 = (padx + 2) / 3;  // virtual cell columns left of the puzzle
+  const int n_entries = 3 * pv.H * a.pad_w;
+  // zero guard entries E[-3..-1] and E[n..n+2]: chunks outside the puzzle's rows clamp onto them
+  if (tid < 3) {
+    E[-3 + tid] = 0;
+    E[n_entries + tid] = 0;
+  }
   build_zone_table(a, pv, env, grid, gmask, E, spos, a.pad_w, c0);
 
-  const int n_entries = 3 * pv.H * a.pad_w;
   const int shift_bytes = 3 * (pady * wpx + padx - 3 * c0);  // may be negative by < 9 bytes per row
   // bias keeps the dividend non-negative; multiple of 9
   const int bias_q = (shift_bytes > 0 ? shift_bytes / 9 : 0) + 2;
@@ -511,48 +516,32 @@ __global__ __launch_bounds__(256) void pw_render_u8_ppc3_kernel(RenderArgs a) {
     const unsigned o3 = static_cast<unsigned>(chunk * 16 - shift_bytes + 9 * bias_q);
     const unsigned qb = o3 / 9u;
     const int b = static_cast<int>(o3 - qb * 9u);
-    const int q0 = static_cast<int>(qb) - bias_q;
-    uint32_t e[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int q = q0 + k;
-      e[k] = (static_cast<unsigned>(q) < static_cast<unsigned>(n_entries)) ? E[q] : 0u;
-    }
-    // 9-byte pixel triples -> 64-bit words
-    uint64_t lo[3];
-    uint32_t hi[2];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const uint64_t r0 = pal[e[k] & 15u], r1 = pal[(e[k] >> 4) & 15u];
-      if (k < 2) {
-        const uint64_t r2 = pal[(e[k] >> 8) & 15u];
-        lo[k] = r0 | (r1 << 24) | (r2 << 48);
-        hi[k] = static_cast<uint32_t>(r2 >> 16);
-      } else {
-        lo[k] = r0 | (r1 << 24);
-      }
-    }
-    // bytes 0..23 of the concatenation, then a byte-granular funnel shift by b (0..8)
-    const uint64_t A = lo[0];
-    const uint64_t B = static_cast<uint64_t>(hi[0]) | (lo[1] << 8);
-    const uint64_t C = (lo[1] >> 56) | (static_cast<uint64_t>(hi[1]) << 8) | (lo[2] << 16);
-    uint64_t w0, w1;
-    if (b == 8) {
-      w0 = B;
-      w1 = C;
-    } else if (b == 0) {
-      w0 = A;
-      w1 = B;
-    } else {
-      const int sh = 8 * b;
-      w0 = (A >> sh) | (B << (64 - sh));
-      w1 = (B >> sh) | (C << (64 - sh));
-    }
+    int q0 = static_cast<int>(qb) - bias_q;
+    q0 = min(max(q0, -3), n_entries);
+    const uint32_t e0 = E[q0], e1 = E[q0 + 1], e2 = E[q0 + 2];
+    // 9-byte pixel triples -> the 24 bytes d0..d5 of the concatenation
+    const uint32_t r00 = pal[e0 & 15u], r01 = pal[(e0 >> 4) & 15u], r02 = pal[(e0 >> 8) & 15u];
+    const uint32_t r10 = pal[e1 & 15u], r11 = pal[(e1 >> 4) & 15u], r12 = pal[(e1 >> 8) & 15u];
+    const uint32_t r20 = pal[e2 & 15u], r21 = pal[(e2 >> 4) & 15u];
+    const uint32_t d0 = r00 | (r01 << 24);
+    const uint32_t d1 = (r01 >> 8) | (r02 << 16);
+    const uint32_t d2 = (r02 >> 16) | (r10 << 8);
+    const uint32_t d3 = r11 | (r12 << 24);
+    const uint32_t d4 = (r12 >> 8) | (r20 << 16);
+    const uint32_t d5 = (r20 >> 16) | (r21 << 8);
+    // byte-granular funnel shift by b (0..8): dword select by b >> 2, then v_alignbyte by b & 3
+    const int sel = b >> 2;
+    const uint32_t s0 = sel == 0 ? d0 : (sel == 1 ? d1 : d2);
+    const uint32_t s1 = sel == 0 ? d1 : (sel == 1 ? d2 : d3);
+    const uint32_t s2 = sel == 0 ? d2 : (sel == 1 ? d3 : d4);
+    const uint32_t s3 = sel == 0 ? d3 : (sel == 1 ? d4 : d5);
+    const uint32_t s4 = sel == 0 ? d4 : d5;  // sel == 2 implies b == 8: byte shift 0, s4 unused
+    const uint32_t bs = static_cast<uint32_t>(b & 3);
     uint4 v;
-    v.x = static_cast<uint32_t>(w0);
-    v.y = static_cast<uint32_t>(w0 >> 32);
-    v.z = static_cast<uint32_t>(w1);
-    v.w = static_cast<uint32_t>(w1 >> 32);
+    v.x = __builtin_amdgcn_alignbyte(s1, s0, bs);
+    v.y = __builtin_amdgcn_alignbyte(s2, s1, bs);
+    v.z = __builtin_amdgcn_alignbyte(s3, s2, bs);
+    v.w = __builtin_amdgcn_alignbyte(s4, s3, bs);
     *reinterpret_cast<uint4*>(out + static_cast<int64_t>(chunk) * 16) = v;
   }
 }
@@ -716,7 +705,7 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   const int cells = s->max_w * s->max_h;
   // grid u32[cells] + pal u32[16] + spos i16[32] + gmask u8[cells, 16-aligned] + E u16[3 * max_h * pad_w]
   e->render_lds = static_cast<size_t>(cells) * 4 + 64 + 64 + ((cells + 15) & ~15) +
-                  static_cast<size_t>(3) * s->max_h * e->pad_w * 2 + 16;
+                  static_cast<size_t>(3) * s->max_h * e->pad_w * 2 + 32;
   for (int i = 0; i < 16; i++) {
     e->pal_rgb[i] = 0;
     for (int c = 0; c < 4; c++) e->pal_f32[i][c] = 0.0f;
