@@ -17,7 +17,7 @@ from ctypes import POINTER, c_char_p, c_int, c_int32, c_int64, c_size_t, c_uint3
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpushworld_amd.so")
+LIB_PATH = os.environ.get("PUSHWORLD_AMD_LIB") or os.path.join(_HERE, "lib", "libpushworld_amd.so")
 
 PW_OK = 0
 PW_EINVAL, PW_EPARSE, PW_EGOAL, PW_ELIMIT, PW_EDEVICE, PW_ENOMEM = -1, -2, -3, -4, -5, -6

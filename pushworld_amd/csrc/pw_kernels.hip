@@ -18,13 +18,19 @@
 //   HBM as coalesced 16-byte stores.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "pw_host.h"
+#include "pw_zone.h"
 
 #define PW_WAVE 64
+#ifndef PW_RENDER_THREADS
+#define PW_RENDER_THREADS 256  // workgroup size of the render kernels (one environment each)
+#endif
 
 struct PwEngine {
   const PwPuzzleSet* set;
@@ -34,6 +40,9 @@ struct PwEngine {
   int obs_h, obs_w;  // pixels
   int64_t obs_bytes;
   size_t render_lds;
+  bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
+  uint16_t* d_estat;       // per puzzle: static zone-colour table in this engine's frame layout
+  uint32_t* d_estat_off;   // byte offset of puzzle p's table in d_estat (16 B aligned)
   uint32_t pal_rgb[16];
   float pal_f32[16][4];
 };
@@ -370,128 +379,107 @@ struct RenderArgs {
   const int32_t* puzzle_id;
   const int8_t* pos;
   uint8_t* obs;
+  const uint16_t* estat;      // static zone tables (engine frame layout)
+  const uint32_t* estat_off;
   int64_t env_stride;
   int32_t batch;
   int32_t np;
   int32_t ppc, bw;
   int32_t pad_h, pad_w;    // frame in cells
-  int32_t grid_cap;        // LDS capacity of the cell grid (cells)
   int32_t obs_bytes;       // bytes of one observation
   uint32_t pal_rgb[16];    // byte0 = R, byte1 = G, byte2 = B
   float pal_f32[16][4];    // uint8 -> float32 / 255 (env_utils.py:65-72), exact IEEE division
 };
 
-// Which of the three horizontal zones (left border | middle | right border) of zone row zy
-// are border pixels for an absent-neighbour mask (puzzle.py:631-638).  bit zx of the result.
-__device__ __forceinline__ uint32_t zone_border_bits(uint32_t m, int zy) {
-  uint32_t u = 0, cl = 0, cr = 0;
-  if (zy == 0) {
-    u = (m >> 2) & 1u;
-    cl = (m >> 4) & 1u;
-    cr = (m >> 5) & 1u;
-  } else if (zy == 2) {
-    u = (m >> 3) & 1u;
-    cl = (m >> 6) & 1u;
-    cr = (m >> 7) & 1u;
-  }
-  const uint32_t b0 = (m & 1u) | u | cl;
-  const uint32_t b2 = ((m >> 1) & 1u) | u | cr;
-  return b0 | (u << 1) | (b2 << 2);
+// LDS layout of the render kernels (dynamic):
+//   [0, 16)        8 zero guard entries in front of E
+//   E              zone table of this environment, uint16 entries, 16 B aligned; followed by >= 3
+//                  zero entries (part of the static table image)
+//   spos, pal, flag
+struct RenderLds {
+  uint16_t* E;
+  int16_t* spos;
+  uint32_t* pal;
+  uint32_t* flag;
+};
+
+__device__ __forceinline__ RenderLds carve_lds(unsigned char* smem, int e_bytes) {
+  RenderLds l;
+  l.E = reinterpret_cast<uint16_t*>(smem + 16);
+  l.spos = reinterpret_cast<int16_t*>(smem + 16 + e_bytes);
+  l.pal = reinterpret_cast<uint32_t*>(smem + 16 + e_bytes + 64);
+  l.flag = l.pal + 16;
+  return l;
 }
 
-// Phases A-C shared by all render kernels: build the per-env zone-colour table
-//   E[(3 * cy + zy) * estride + cx + c0]  = colour(zx=0) | colour(zx=1) << 4 | colour(zx=2) << 8
-// in LDS.  `estride` columns per row, the puzzle's own columns start at c0; the remaining
-// entries are PW_C_PAD.
-__device__ __forceinline__ void build_zone_table(const RenderArgs& a, const PuzzleView& pv, int env, uint32_t* grid,
-                                                 uint8_t* gmask, uint16_t* E, int16_t* spos, int estride, int c0) {
+// Writes the three sub-row entries of one movable cell over the static table.
+__device__ __forceinline__ void patch_cell(const PuzzleView& pv, uint16_t* E, const int16_t* spos, uint32_t c,
+                                           int estride, int c0) {
+  const int obj = c >> 24;
+  const int p = static_cast<uint16_t>(spos[obj]);
+  const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
+  const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
+  if (static_cast<unsigned>(x) >= static_cast<unsigned>(pv.W) || static_cast<unsigned>(y) >= static_cast<unsigned>(pv.H))
+    return;
+  const uint32_t kind = obj == 0 ? 3u : (obj <= pv.G ? 4u : 5u);
+  const uint32_t om = (c >> 16) & 0xffu;
+#pragma unroll
+  for (int zy = 0; zy < 3; zy++) {
+    const int idx = (3 * y + zy) * estride + x + c0;
+    const uint32_t gb = pw_entry_goal_bits(E[idx]);  // goal outlines stay on top (puzzle.py:458)
+    E[idx] = static_cast<uint16_t>(pw_zone_entry(kind, pw_zone_border_bits(om, zy), gb));
+  }
+}
+
+// Per-environment zone table: the puzzle's static table (walls, agent walls, background, goal
+// outlines; precomputed per engine) is copied into LDS with 16-byte loads and the cells under
+// the movables are patched in painter order (puzzle.py:453-458).  In an overlap-free state
+// (always, under legal play) no two movables share a cell and the patches are independent;
+// otherwise objects are applied one after the other so that a higher index wins.
+__device__ __forceinline__ void build_zone_table(const RenderArgs& a, const PuzzleView& pv, int pid, int env,
+                                                 const RenderLds& l, int estride, int c0) {
   const int tid = threadIdx.x;
-  const int W = pv.W, H = pv.H;
-  const int cells = W * H;
-  if (tid < a.np) spos[tid] = reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + tid];
-  for (int i = tid; i < cells; i += blockDim.x) {
-    const uint32_t code = pv.stat[i];
-    grid[i] = code & 0x00FFFFFFu;
-    gmask[i] = static_cast<uint8_t>(code >> PW_CODE_GOAL_SHIFT);
+  const int lane = tid & (PW_WAVE - 1);
+  const int n_entries = 3 * pv.H * estride;
+  const int n16 = (2 * (n_entries + 3) + 15) >> 4;
+  const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[pid]);
+  uint4* dst = reinterpret_cast<uint4*>(l.E);
+  for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
+  if (tid < 16) l.pal[tid] = a.pal_rgb[tid];
+  if (tid >= 64 && tid < 72) l.E[tid - 72] = 0;  // guard entries E[-8..-1]
+  if (tid < PW_WAVE) {
+    // wave 0: positions to LDS + overlap check of the state
+    int xy = 0;
+    if (lane < a.np) xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + lane]);
+    if (lane < 32) l.spos[lane] = static_cast<int16_t>(xy);
+    const EnvBoards b = load_boards(pv, xy, lane);
+    if (lane == 0) l.flag[0] = b.legal ? 1u : 0u;
   }
   __syncthreads();
-  // movables in painter order (puzzle.py:457): a higher object index wins a shared cell
-  for (int m = tid; m < pv.n_mcells; m += blockDim.x) {
-    const uint32_t c = pv.mcells[m];
-    const int obj = c >> 24;
-    const int p = static_cast<uint16_t>(spos[obj]);
-    const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
-    const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
-    const uint32_t kind = obj == 0 ? 3u : (obj <= pv.G ? 4u : 5u);
-    const uint32_t val = (static_cast<uint32_t>(obj + 1) << PW_CODE_PRIO_SHIFT) | (kind << PW_CODE_KIND_SHIFT) | ((c >> 16) & 0xffu);
-    if (static_cast<unsigned>(x) < static_cast<unsigned>(W) && static_cast<unsigned>(y) < static_cast<unsigned>(H))
-      atomicMax(&grid[y * W + x], val);
-  }
-  __syncthreads();
-  const int ecells = H * estride;
-  for (int i = tid; i < ecells; i += blockDim.x) {
-    const int cy = i / estride;
-    const int cv = i - cy * estride;
-    const int cx = cv - c0;
-    uint32_t e0 = 0, e1 = 0, e2 = 0;
-    if (static_cast<unsigned>(cx) < static_cast<unsigned>(W)) {
-      const uint32_t code = grid[cy * W + cx];
-      const uint32_t gm = gmask[cy * W + cx];
-      const uint32_t kind = (code >> PW_CODE_KIND_SHIFT) & 0xfu;
-      const uint32_t fill = kind ? 2u * kind : static_cast<uint32_t>(PW_C_BACKGROUND);
-      const uint32_t edge = kind ? 2u * kind + 1u : static_cast<uint32_t>(PW_C_BACKGROUND);
-      const uint32_t om = code & 0xffu;
-      uint32_t ent[3];
-#pragma unroll
-      for (int zy = 0; zy < 3; zy++) {
-        const uint32_t ob = zone_border_bits(om, zy);
-        const uint32_t gb = zone_border_bits(gm, zy);
-        uint32_t v = 0;
-#pragma unroll
-        for (int zx = 0; zx < 3; zx++) {
-          uint32_t col = ((ob >> zx) & 1u) ? edge : fill;
-          if ((gb >> zx) & 1u) col = PW_C_GOAL_BORDER;
-          v |= col << (4 * zx);
-        }
-        ent[zy] = v;
+  if (l.flag[0]) {
+    for (int m = tid; m < pv.n_mcells; m += blockDim.x) patch_cell(pv, l.E, l.spos, pv.mcells[m], estride, c0);
+  } else {
+    for (int j = 0; j < pv.N; j++) {
+      for (int m = tid; m < pv.n_mcells; m += blockDim.x) {
+        const uint32_t c = pv.mcells[m];
+        if (static_cast<int>(c >> 24) == j) patch_cell(pv, l.E, l.spos, c, estride, c0);
       }
-      e0 = ent[0];
-      e1 = ent[1];
-      e2 = ent[2];
+      __syncthreads();
     }
-    E[(3 * cy + 0) * estride + cv] = static_cast<uint16_t>(e0);
-    E[(3 * cy + 1) * estride + cv] = static_cast<uint16_t>(e1);
-    E[(3 * cy + 2) * estride + cv] = static_cast<uint16_t>(e2);
   }
   __syncthreads();
-}
-
-__device__ __forceinline__ void carve_lds(const RenderArgs& a, unsigned char* smem, uint32_t*& grid, uint16_t*& E,
-                                          uint8_t*& gmask, int16_t*& spos, uint32_t*& pal) {
-  grid = reinterpret_cast<uint32_t*>(smem);
-  pal = grid + a.grid_cap;
-  spos = reinterpret_cast<int16_t*>(pal + 16);
-  gmask = reinterpret_cast<uint8_t*>(spos + 32);
-  E = reinterpret_cast<uint16_t*>(gmask + ((a.grid_cap + 15) & ~15)) + 4;  // 4 guard entries in front
 }
 
 // Fast path: uint8 observation, pixels_per_cell = 3, border_width = 1 (zones == pixels).
 // A zone-table entry is then exactly 3 pixels = 9 bytes of one image row, and because the
 // frame is pad_w * 3 pixels wide the table (row stride pad_w) is the image itself in
 // 9-byte units: output byte o belongs to entry floor((o - shift) / 9).
-__global__ __launch_bounds__(256) void pw_render_u8_ppc3_kernel(RenderArgs a) {
+__global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_u8_ppc3_kernel(RenderArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t* grid;
-  uint16_t* E;
-  uint8_t* gmask;
-  int16_t* spos;
-  uint32_t* pal;
-  carve_lds(a, smem, grid, E, gmask, spos, pal);
   const int env = blockIdx.x;
   const int tid = threadIdx.x;
   const int pid = a.puzzle_id[env];
   const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
-  if (tid < 16) pal[tid] = a.pal_rgb[tid];
 
   // pixel padding of env_utils.py:75-91 (left/top get the floor half)
   const int wpx = a.pad_w * 3;
@@ -499,12 +487,10 @@ __global__ __launch_bounds__(256) void pw_render_u8_ppc3_kernel(RenderArgs a) {
   const int padx = (a.pad_w - pv.W) * 3 / 2;
   const int c0 = (padx + 2) / 3;  // virtual cell columns left of the puzzle
   const int n_entries = 3 * pv.H * a.pad_w;
-  // zero guard entries E[-3..-1] and E[n..n+2]: chunks outside the puzzle's rows clamp onto them
-  if (tid < 3) {
-    E[-3 + tid] = 0;
-    E[n_entries + tid] = 0;
-  }
-  build_zone_table(a, pv, env, grid, gmask, E, spos, a.pad_w, c0);
+  const RenderLds l = carve_lds(smem, ((2 * (n_entries + 3) + 15) >> 4) << 4);
+  build_zone_table(a, pv, pid, env, l, a.pad_w, c0);
+  const uint16_t* E = l.E;
+  const uint32_t* pal = l.pal;
 
   const int shift_bytes = 3 * (pady * wpx + padx - 3 * c0);  // may be negative by < 9 bytes per row
   // bias keeps the dividend non-negative; multiple of 9
@@ -512,7 +498,7 @@ __global__ __launch_bounds__(256) void pw_render_u8_ppc3_kernel(RenderArgs a) {
   const int n_chunks = (a.obs_bytes + 15) >> 4;
   uint8_t* out = a.obs + static_cast<int64_t>(env) * a.env_stride;
 
-  for (int chunk = tid; chunk < n_chunks; chunk += 256) {
+  for (int chunk = tid; chunk < n_chunks; chunk += PW_RENDER_THREADS) {
     const unsigned o3 = static_cast<unsigned>(chunk * 16 - shift_bytes + 9 * bias_q);
     const unsigned qb = o3 / 9u;
     const int b = static_cast<int>(o3 - qb * 9u);
@@ -549,20 +535,17 @@ __global__ __launch_bounds__(256) void pw_render_u8_ppc3_kernel(RenderArgs a) {
 // Generic path: any pixels_per_cell / border_width, uint8 or float32 elements.
 // One thread produces 16 bytes (16 uint8 or 4 float32 channel values) per iteration.
 template <typename T>
-__global__ __launch_bounds__(256) void pw_render_generic_kernel(RenderArgs a) {
+__global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_generic_kernel(RenderArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t* grid;
-  uint16_t* E;
-  uint8_t* gmask;
-  int16_t* spos;
-  uint32_t* pal;
-  carve_lds(a, smem, grid, E, gmask, spos, pal);
   const int env = blockIdx.x;
   const int tid = threadIdx.x;
   const int pid = a.puzzle_id[env];
   const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
-  if (tid < 16) pal[tid] = a.pal_rgb[tid];
-  build_zone_table(a, pv, env, grid, gmask, E, spos, pv.W, 0);
+  const int n_entries = 3 * pv.H * pv.W;
+  const RenderLds l = carve_lds(smem, ((2 * (n_entries + 3) + 15) >> 4) << 4);
+  build_zone_table(a, pv, pid, env, l, pv.W, 0);
+  const uint16_t* E = l.E;
+  const uint32_t* pal = l.pal;
 
   constexpr int kElems = 16 / sizeof(T);
   const int ppc = a.ppc, bw = a.bw;
@@ -573,7 +556,7 @@ __global__ __launch_bounds__(256) void pw_render_generic_kernel(RenderArgs a) {
   const int n_chunks = (a.obs_bytes + 15) >> 4;
   uint8_t* out = a.obs + static_cast<int64_t>(env) * a.env_stride;
 
-  for (int chunk = tid; chunk < n_chunks; chunk += 256) {
+  for (int chunk = tid; chunk < n_chunks; chunk += PW_RENDER_THREADS) {
     const int elem0 = chunk * kElems;
     int pix = elem0 / 3;
     int ch = elem0 - pix * 3;
@@ -663,7 +646,8 @@ int fill_render_args(const PwEngine* e, const int32_t* puzzle_id, const int8_t* 
   ra->bw = e->cfg.border_width;
   ra->pad_h = e->pad_h;
   ra->pad_w = e->pad_w;
-  ra->grid_cap = e->set->max_w * e->set->max_h;
+  ra->estat = e->d_estat;
+  ra->estat_off = e->d_estat_off;
   ra->obs_bytes = static_cast<int32_t>(e->obs_bytes);
   for (int i = 0; i < 16; i++) {
     ra->pal_rgb[i] = e->pal_rgb[i];
@@ -702,10 +686,38 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
     delete e;
     return pw_fail(PW_ELIMIT, "observation larger than 1 GiB");
   }
-  const int cells = s->max_w * s->max_h;
-  // grid u32[cells] + pal u32[16] + spos i16[32] + gmask u8[cells, 16-aligned] + E u16[3 * max_h * pad_w]
-  e->render_lds = static_cast<size_t>(cells) * 4 + 64 + 64 + ((cells + 15) & ~15) +
-                  static_cast<size_t>(3) * s->max_h * e->pad_w * 2 + 32;
+  e->fast_u8_ppc3 = cfg->obs_dtype == PW_OBS_U8 && cfg->pixels_per_cell == 3 && cfg->border_width == 1;
+  e->d_estat = nullptr;
+  e->d_estat_off = nullptr;
+  // Static zone-colour tables (walls, agent walls, background, goal outlines) of every puzzle in
+  // the layout the render kernel of this engine streams from: row stride pad_w with the puzzle
+  // shifted by c0 virtual columns for the 3-pixel fast path, row stride W otherwise.
+  std::vector<uint16_t> estat;
+  std::vector<uint32_t> estat_off(s->count);
+  size_t max_e_bytes = 0;
+  for (int p = 0; p < s->count; p++) {
+    const PwPuzzleHeader& h = s->headers[p];
+    const int W = h.W, H = h.H;
+    const int estride = e->fast_u8_ppc3 ? e->pad_w : W;
+    const int c0 = e->fast_u8_ppc3 ? ((e->pad_w - W) * 3 / 2 + 2) / 3 : 0;
+    const uint32_t* codes = reinterpret_cast<const uint32_t*>(s->blob.data() + h.base + h.off_static);
+    const size_t n_entries = static_cast<size_t>(3) * H * estride;
+    const size_t e_bytes = ((2 * (n_entries + 3) + 15) >> 4) << 4;
+    max_e_bytes = std::max(max_e_bytes, e_bytes);
+    estat_off[p] = static_cast<uint32_t>(estat.size() * 2);
+    const size_t first = estat.size();
+    estat.resize(first + e_bytes / 2, 0);
+    for (int cy = 0; cy < H; cy++)
+      for (int cx = 0; cx < W; cx++) {
+        const uint32_t code = codes[cy * W + cx];
+        const uint32_t kind = (code >> PW_CODE_KIND_SHIFT) & 0xfu;
+        const uint32_t om = code & 0xffu, gm = code >> PW_CODE_GOAL_SHIFT;
+        for (int zy = 0; zy < 3; zy++)
+          estat[first + static_cast<size_t>(3 * cy + zy) * estride + cx + c0] =
+              static_cast<uint16_t>(pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_zone_border_bits(gm, zy)));
+      }
+  }
+  e->render_lds = 16 + max_e_bytes + 64 + 64 + 16;
   for (int i = 0; i < 16; i++) {
     e->pal_rgb[i] = 0;
     for (int c = 0; c < 4; c++) e->pal_f32[i][c] = 0.0f;
@@ -720,6 +732,11 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
     }
   }
   hipError_t err = hipSetDevice(s->device);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_estat), estat.size() * 2);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_estat_off), estat_off.size() * 4);
+  if (err == hipSuccess) err = hipMemcpy(e->d_estat, estat.data(), estat.size() * 2, hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(e->d_estat_off, estat_off.data(), estat_off.size() * 4, hipMemcpyHostToDevice);
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_u8_ppc3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
@@ -730,14 +747,20 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_generic_kernel<float>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
   if (err != hipSuccess) {
-    delete e;
-    return pw_fail(PW_EDEVICE, std::string("engine setup failed: ") + hipGetErrorString(err));
+    std::string msg = std::string("engine setup failed: ") + hipGetErrorString(err);
+    pw_engine_destroy(e);
+    return pw_fail(PW_EDEVICE, msg);
   }
   *out = e;
   return PW_OK;
 }
 
-void pw_engine_destroy(PwEngine* e) { delete e; }
+void pw_engine_destroy(PwEngine* e) {
+  if (!e) return;
+  if (e->d_estat) (void)hipFree(e->d_estat);
+  if (e->d_estat_off) (void)hipFree(e->d_estat_off);
+  delete e;
+}
 
 int pw_engine_npad(const PwEngine* e) { return e ? e->np : pw_fail(PW_EINVAL, "null engine"); }
 
@@ -788,8 +811,8 @@ int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* ob
   int rc = fill_render_args(e, puzzle_id, pos, obs, env_stride_bytes, batch, &ra);
   if (rc != PW_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(batch)), block(256);
-  if (e->cfg.obs_dtype == PW_OBS_U8 && e->cfg.pixels_per_cell == 3 && e->cfg.border_width == 1)
+  const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
+  if (e->fast_u8_ppc3)
     hipLaunchKernelGGL(pw_render_u8_ppc3_kernel, grid, block, e->render_lds, st, ra);
   else if (e->cfg.obs_dtype == PW_OBS_U8)
     hipLaunchKernelGGL(pw_render_generic_kernel<uint8_t>, grid, block, e->render_lds, st, ra);

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3: N step+render passes of the C3 workload, nothing else timed.
+
+    rocprofv3 --kernel-trace --stats -d out -o name -- python tools/profile_hotpath.py --steps 20
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -o name -- python tools/profile_hotpath.py
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from pushworld_amd.puzzle import PushWorldPuzzle  # noqa: E402
+from pushworld_amd.vec_env import VecPushWorld  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=65536)
+    ap.add_argument("--ppc", type=int, default=3)
+    ap.add_argument("--bw", type=int, default=1)
+    ap.add_argument("--obs", default="uint8")
+    args = ap.parse_args()
+    paths = bench.level1_paths()
+    B = args.envs
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, border_width=args.bw,
+                       pixels_per_cell=args.ppc, observation=args.obs, device=0, autoreset=True)
+    vec.reset()
+    gen = torch.Generator(device=vec.device)
+    gen.manual_seed(1)
+    acts = torch.randint(0, 4, (args.steps, B), generator=gen, device=vec.device, dtype=torch.uint8)
+    torch.cuda.synchronize()
+    for t in range(args.steps):
+        vec.step(acts[t])
+    torch.cuda.synchronize()
+    print("done", args.steps, "steps of", B, "envs; obs bytes/env", vec.engine.obs_bytes)
+
+
+if __name__ == "__main__":
+    main()
