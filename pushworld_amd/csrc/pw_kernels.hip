@@ -248,27 +248,26 @@ struct StepArgs {
   int32_t np;
 };
 
-__global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
-  const int lane = threadIdx.x & (PW_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-  const int env = blockIdx.x * (256 / PW_WAVE) + wave;
-  if (env >= a.batch) return;
+// One wavefront advances one environment (all lanes of the wave must call this).
+//   xy_out     lane j = packed (x | y << 8) of object j after the call
+//   legal_out  true when the resulting state is known to be overlap-free (legal play keeps it
+//              so: pushed objects move rigidly into free cells); false = unknown
+__device__ __forceinline__ void step_one_env(const StepArgs& a, int env, int lane, const PuzzleView& pv, int& xy_out,
+                                             bool& legal_out) {
   const int NP = a.np;
-
   // first-level loads, all independent
-  const int pid = __builtin_amdgcn_readfirstlane(a.puzzle_id[env]);
   const int act = __builtin_amdgcn_readfirstlane(static_cast<int>(a.actions[env]));
   const int was_done = __builtin_amdgcn_readfirstlane(static_cast<int>(a.term[env] | a.trunc[env]));
   const int steps_in = __builtin_amdgcn_readfirstlane(a.steps[env]);
   int16_t* prow = reinterpret_cast<int16_t*>(a.pos) + static_cast<int64_t>(env) * NP;
   int xy = 0;  // coalesced load of the packed (x, y) int8 pairs: lane j holds object j
   if (lane < NP) xy = static_cast<uint16_t>(prow[lane]);
-
-  const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
+  legal_out = false;
 
   if ((a.flags & PW_STEP_AUTORESET) && was_done) {
     // next-step autoreset: this call is the reset() of a finished episode
-    if (lane < NP) prow[lane] = lane < pv.N ? reinterpret_cast<const int16_t*>(pv.h->init)[lane] : int16_t(0);
+    xy = (lane < pv.N) ? static_cast<int>(reinterpret_cast<const uint16_t*>(pv.h->init)[lane]) : 0;
+    if (lane < NP) prow[lane] = static_cast<int16_t>(xy);
     if (lane == 0) {
       a.steps[env] = 0;
       a.term[env] = 0;
@@ -276,6 +275,7 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
       if (a.reward) a.reward[env] = 0.0;
       if (a.dgoals) a.dgoals[env] = 0;
     }
+    xy_out = xy;
     return;
   }
   if (act > 3) {  // not in Discrete(4): flag and leave the env untouched (gym_env.py:195-196)
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
       a.term[env] = 0xFF;
       a.trunc[env] = 0xFF;
     }
+    xy_out = xy;
     return;
   }
 
@@ -315,6 +316,20 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
     if (a.reward) a.reward[env] = terminated ? 10.0 : static_cast<double>(after - before) - 0.01;
     if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(after - before);
   }
+  xy_out = lane < pv.N ? nxy : 0;
+  legal_out = b.legal;
+}
+
+__global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
+  const int lane = threadIdx.x & (PW_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int env = blockIdx.x * (256 / PW_WAVE) + wave;
+  if (env >= a.batch) return;
+  const int pid = __builtin_amdgcn_readfirstlane(a.puzzle_id[env]);
+  const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
+  int xy;
+  bool legal;
+  step_one_env(a, env, lane, pv, xy, legal);
 }
 
 // ------------------------------------------------------------------------------------
@@ -389,6 +404,8 @@ struct RenderArgs {
   int32_t obs_bytes;       // bytes of one observation
   uint32_t pal_rgb[16];    // byte0 = R, byte1 = G, byte2 = B
   float pal_f32[16][4];    // uint8 -> float32 / 255 (env_utils.py:65-72), exact IEEE division
+  int32_t do_step;         // fused pw_step_render: wave 0 advances the environment first
+  StepArgs step;
 };
 
 // LDS layout of the render kernels (dynamic):
@@ -448,12 +465,17 @@ __device__ __forceinline__ void build_zone_table(const RenderArgs& a, const Puzz
   if (tid < 16) l.pal[tid] = a.pal_rgb[tid];
   if (tid >= 64 && tid < 72) l.E[tid - 72] = 0;  // guard entries E[-8..-1]
   if (tid < PW_WAVE) {
-    // wave 0: positions to LDS + overlap check of the state
+    // wave 0: (fused step,) positions to LDS + overlap check of the state to draw
     int xy = 0;
-    if (lane < a.np) xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + lane]);
+    bool legal;
+    if (a.do_step) {
+      step_one_env(a.step, env, lane, pv, xy, legal);
+    } else {
+      if (lane < a.np) xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + lane]);
+      legal = load_boards(pv, xy, lane).legal;
+    }
     if (lane < 32) l.spos[lane] = static_cast<int16_t>(xy);
-    const EnvBoards b = load_boards(pv, xy, lane);
-    if (lane == 0) l.flag[0] = b.legal ? 1u : 0u;
+    if (lane == 0) l.flag[0] = legal ? 1u : 0u;
   }
   __syncthreads();
   if (l.flag[0]) {
@@ -649,6 +671,7 @@ int fill_render_args(const PwEngine* e, const int32_t* puzzle_id, const int8_t* 
   ra->estat = e->d_estat;
   ra->estat_off = e->d_estat_off;
   ra->obs_bytes = static_cast<int32_t>(e->obs_bytes);
+  ra->do_step = 0;
   for (int i = 0; i < 16; i++) {
     ra->pal_rgb[i] = e->pal_rgb[i];
     for (int c = 0; c < 4; c++) ra->pal_f32[i][c] = e->pal_f32[i][c];
@@ -790,14 +813,33 @@ int pw_reset(PwEngine* e, const int32_t* puzzle_id, const uint8_t* mask, int8_t*
   return check_launch("pw_reset");
 }
 
+static int fill_step_args(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,
+                          double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, int32_t batch,
+                          uint32_t flags, StepArgs* a) {
+  if (!e || !puzzle_id || !actions || !pos || !steps || !terminated || !truncated)
+    return pw_fail(PW_EINVAL, "null argument");
+  *a = StepArgs{e->set->d_headers, e->set->d_blob, puzzle_id, actions, pos, steps, reward, dgoals,
+                terminated, truncated, batch, e->cfg.max_steps, flags, e->np};
+  return PW_OK;
+}
+
+static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipStream_t st) {
+  const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
+  if (e->fast_u8_ppc3)
+    hipLaunchKernelGGL(pw_render_u8_ppc3_kernel, grid, block, e->render_lds, st, ra);
+  else if (e->cfg.obs_dtype == PW_OBS_U8)
+    hipLaunchKernelGGL(pw_render_generic_kernel<uint8_t>, grid, block, e->render_lds, st, ra);
+  else
+    hipLaunchKernelGGL(pw_render_generic_kernel<float>, grid, block, e->render_lds, st, ra);
+}
+
 int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,
             double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, int32_t batch,
             uint32_t flags, void* stream) {
-  if (!e || !puzzle_id || !actions || !pos || !steps || !terminated || !truncated)
-    return pw_fail(PW_EINVAL, "null argument");
+  StepArgs a;
+  int rc = fill_step_args(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, batch, flags, &a);
+  if (rc != PW_OK) return rc;
   if (batch <= 0) return PW_OK;
-  StepArgs a{e->set->d_headers, e->set->d_blob, puzzle_id, actions, pos, steps, reward, dgoals,
-             terminated, truncated, batch, e->cfg.max_steps, flags, e->np};
   const unsigned blocks = static_cast<unsigned>((batch + 3) / 4);
   hipLaunchKernelGGL(pw_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("pw_step");
@@ -810,23 +852,28 @@ int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* ob
   RenderArgs ra;
   int rc = fill_render_args(e, puzzle_id, pos, obs, env_stride_bytes, batch, &ra);
   if (rc != PW_OK) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
-  if (e->fast_u8_ppc3)
-    hipLaunchKernelGGL(pw_render_u8_ppc3_kernel, grid, block, e->render_lds, st, ra);
-  else if (e->cfg.obs_dtype == PW_OBS_U8)
-    hipLaunchKernelGGL(pw_render_generic_kernel<uint8_t>, grid, block, e->render_lds, st, ra);
-  else
-    hipLaunchKernelGGL(pw_render_generic_kernel<float>, grid, block, e->render_lds, st, ra);
+  launch_render(e, ra, batch, static_cast<hipStream_t>(stream));
   return check_launch("pw_render");
 }
 
+// One launch: wave 0 of every workgroup advances its environment (pw_step semantics), the
+// whole workgroup then draws the new state.
 int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,
                    double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, void* obs,
                    int64_t env_stride_bytes, int32_t batch, uint32_t flags, void* stream) {
-  int rc = pw_step(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, batch, flags, stream);
+  if (!e) return pw_fail(PW_EINVAL, "null engine");
+  RenderArgs ra;
+  int rc = fill_step_args(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, batch, flags,
+                          &ra.step);
   if (rc != PW_OK) return rc;
-  return pw_render(e, puzzle_id, pos, obs, env_stride_bytes, batch, stream);
+  if (batch <= 0) return PW_OK;
+  const StepArgs sa = ra.step;
+  rc = fill_render_args(e, puzzle_id, pos, obs, env_stride_bytes, batch, &ra);
+  if (rc != PW_OK) return rc;
+  ra.step = sa;
+  ra.do_step = 1;
+  launch_render(e, ra, batch, static_cast<hipStream_t>(stream));
+  return check_launch("pw_step_render");
 }
 
 int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ, uint32_t* moved, uint8_t* goal,

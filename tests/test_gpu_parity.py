@@ -185,3 +185,50 @@ def test_full_small_images(golden, puzzles, torch_mod):
         want = golden.images[key]
         assert img.shape == want.shape
         assert (img == want).all(), (key, np.argwhere(img != want)[:5])
+
+
+def test_fused_step_render_matches_reference(golden, puzzles, torch_mod):
+    """pw_step_render (ONE launch: step in wave 0 + render) on a mixed batch: states, rewards,
+    flags equal the golden trajectories and the observation equals the oracle's image of the
+    reference state at every checked step (uint8, ppc 3, frame = batch maximum)."""
+    torch = torch_mod
+    from oracle import c_oracle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith("bench:level1/")][::3] + ["pytest:trivial_tool.pwp"]
+    pool = [puzzles[k] for k in keys]
+    envs = []
+    for pi, k in enumerate(keys):
+        for seq in golden.sequences(k):
+            if seq[0] in ("plan", "rand"):
+                envs.append((pi, k, seq))
+    B = len(envs)
+    T = 120
+    vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=None, pixels_per_cell=3, border_width=1,
+                       observation="uint8", device=0)
+    obs0 = vec.reset()
+    oracles = {k: c_oracle.COraclePuzzle(golden.text(k)) for k in keys}
+    fh, fw = vec.engine.obs_shape[0] // 3, vec.engine.obs_shape[1] // 3
+    for b in (0, B // 2, B - 1):
+        o = oracles[envs[b][1]]
+        assert (obs0[b].cpu().numpy() == o.observation(o.initial_state, fh, fw, 3, 1, dtype="u8")).all()
+    actions = np.zeros((T, B), np.uint8)
+    for b, (_, _, seq) in enumerate(envs):
+        n = min(T, len(seq[1]))
+        actions[:n, b] = seq[1][:n]
+    acts_dev = torch.as_tensor(actions).to(vec.device)
+    for t in range(T):
+        obs, r, te, tr = vec.step(acts_dev[t])
+        pos = vec.pos.cpu().numpy()
+        rr, tt = r.cpu().numpy(), te.cpu().numpy()
+        img = obs.cpu().numpy() if t % 17 == 0 or t == T - 1 else None
+        for b, (pi, k, seq) in enumerate(envs):
+            if t >= len(seq[1]):
+                continue
+            want = seq[3][t]
+            assert (pos[b, : want.shape[0]] == want.astype(np.int8)).all(), (k, seq[0], t)
+            assert rr[b].view(np.uint64) == seq[4][t].view(np.uint64) and tt[b] == seq[5][t], (k, seq[0], t)
+            if img is not None and b % 5 == 0:
+                o = oracles[k]
+                st = tuple(map(tuple, want.tolist()))
+                assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
