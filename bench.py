@@ -100,7 +100,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from pushworld_amd import _capi
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.vec_env import VecPushWorld
 
@@ -151,13 +150,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([B * K], dtype=torch.int64, device=dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    total_steps = int(cnt.item())
+    # the ONLY collective of the whole job: SUM of counters, MAX of the window (a few bytes)
+    from pushworld_amd.sharding import reduce_counters
+
+    counters, elapsed = reduce_counters({"env_steps": B * K}, elapsed, device=dev)
+    total_steps = counters["env_steps"]
 
     if rank == 0:
         n_obj = eng.np

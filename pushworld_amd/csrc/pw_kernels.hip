@@ -510,6 +510,15 @@ __global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_u8_ppc3_kernel(Re
   const int c0 = (padx + 2) / 3;  // virtual cell columns left of the puzzle
   const int n_entries = 3 * pv.H * a.pad_w;
   const RenderLds l = carve_lds(smem, ((2 * (n_entries + 3) + 15) >> 4) << 4);
+#ifdef PW_STAGGER
+  // De-correlate the first generation of workgroups: all workgroups take equally long, so
+  // without this the whole chip alternates between "everyone in the preamble" and "everyone
+  // streaming" for the entire launch.
+  if (blockIdx.x < PW_STAGGER) {
+    const unsigned h = (blockIdx.x * 2654435761u) >> 26;
+    for (unsigned i = 0; i < h; i++) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   build_zone_table(a, pv, pid, env, l, a.pad_w, c0);
   const uint16_t* E = l.E;
   const uint32_t* pal = l.pal;

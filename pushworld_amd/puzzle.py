@@ -227,6 +227,30 @@ class PushWorldPuzzle:
         hist = term.cpu().numpy()
         return bool(hist[-1] == 1 and not hist[:-1].any())
 
+    def expand4(self, states):
+        """Planner successor expansion (cpp/include/search/best_first_search.h:76-78 calling
+        PushWorldPuzzle::getNextState / satisfiesGoal, cpp/src/pushworld_puzzle.cc:386-469) for
+        F states at once.
+
+        Args:
+            states: int32 array/tensor [F, N] of ``Position2D = x * 10000 + y`` values
+                (pushworld_puzzle.h:32-37) in this puzzle's object order.
+
+        Returns ``(succ int32 [F, 4, N], moved uint32-as-int32 [F, 4] bit masks of
+        moved_object_indices, goal uint8 [F, 4])`` as torch tensors on the device.
+        """
+        eng = self._engine()
+        st = torch.as_tensor(states, dtype=torch.int32).to(eng.device).contiguous()
+        if st.dim() != 2 or st.shape[1] != self.num_movables:
+            raise ValueError(f"states must have shape [F, {self.num_movables}]")
+        F = st.shape[0]
+        succ = torch.empty((F, 4, self.num_movables), dtype=torch.int32, device=eng.device)
+        moved = torch.empty((F, 4), dtype=torch.int32, device=eng.device)
+        goal = torch.empty((F, 4), dtype=torch.uint8, device=eng.device)
+        if F:
+            eng.expand4(0, st, succ, moved, goal)
+        return succ, moved, goal
+
     # ---------------------------------------------------------------- rendering
     def render(self, state: State, border_width: int = DEFAULT_BORDER_WIDTH,
                pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL) -> np.ndarray:

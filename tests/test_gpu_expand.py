@@ -1,0 +1,145 @@
+"""-m gpu: config C5 -- batched 4-action successor expansion in the C++ reference's object
+order and Position2D encoding, checked against the oracle (order="cpp") and the C++
+reference's own known answers (cpp/test/test_pushworld_puzzle.cc, cpp/test/search/*)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "puzzles", "ref_cpp")
+
+
+def p2d(state):
+    return [x * 10000 + y for (x, y) in state]
+
+
+def bfs(puzzle, max_states):
+    """Breadth-first closure with the GPU expansion; returns the visited states (in discovery
+    order) and per-state successor / moved / goal arrays."""
+    init = tuple(p2d(puzzle.initial_state))
+    index = {init: 0}
+    order = [init]
+    succs, moveds, goals = [], [], []
+    lo = 0
+    while lo < len(order) and len(order) < max_states:
+        layer = np.array(order[lo:], dtype=np.int32)
+        lo = len(order)
+        s, m, g = puzzle.expand4(layer)
+        s, m, g = s.cpu().numpy(), m.cpu().numpy().astype(np.uint32), g.cpu().numpy()
+        succs.append(s)
+        moveds.append(m)
+        goals.append(g)
+        for row in s.reshape(-1, s.shape[-1]):
+            t = tuple(int(v) for v in row)
+            if t not in index:
+                index[t] = len(order)
+                order.append(t)
+    n = sum(len(x) for x in succs)
+    return order, np.concatenate(succs), np.concatenate(moveds), np.concatenate(goals), n
+
+
+@pytest.mark.parametrize("key", [
+    "cpptest:trivial.pwp", "cpptest:trivial_tool.pwp", "cpptest:trivial_tool2.pwp", "cpptest:easy_search.pwp",
+    "cpptest:blocked_transitive_pushing1.pwp", "cpptest:blocked_transitive_pushing2.pwp",
+    "cpptest:necessary_transitive_pushing3.pwp", "cpptest:multiple_goals.pwp", "cpptest:file_parsing.pwp",
+    "bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp", "bench:level4/Four Pistons.pwp",
+    "bench:level1/Pulling.pwp", "bench:level3/Jump In The Tetris Line.pwp",
+])
+def test_bfs_layers_match_oracle(golden, key):
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    if key not in golden.meta:
+        pytest.skip("puzzle not in the fixture set")
+    text = golden.text(key)
+    pz = PushWorldPuzzle(text=text, order="cpp")
+    oz = c_oracle.COraclePuzzle(text, order="cpp")
+    assert tuple(pz.initial_state) == tuple(oz.initial_state)
+    order, succ, moved, goal, n = bfs(pz, 6000)
+    assert n >= 1
+    for i in range(n):
+        st = tuple((v // 10000, v % 10000) for v in order[i])
+        for a in range(4):
+            nxt, mv = oz.get_next_state_moved(st, a)
+            assert succ[i, a].tolist() == p2d(nxt), (key, i, a)
+            mask = 0
+            for k in mv:
+                mask |= 1 << k
+            assert int(moved[i, a]) == mask, (key, i, a)  # agent first, ascending; empty if blocked
+            assert bool(goal[i, a]) == oz.py.is_goal_state(nxt), (key, i, a)
+
+
+def test_cpp_known_answers():
+    """cpp/test/test_pushworld_puzzle.cc:260-394 (trivial.pwp walk), cpp/test/search/
+    test_best_first_search.cc:117 (no_solution.pwp has exactly 9 reachable states) and :122
+    (the shortest plan of trivial.pwp is R, D, R, U)."""
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    L, R, U, D = 0, 1, 2, 3
+    pz = PushWorldPuzzle(os.path.join(CPP, "trivial.pwp"), order="cpp")
+    state = np.array([p2d(pz.initial_state)], dtype=np.int32)
+    walk = [(L, (1, 2), (2, 2), False), (U, (1, 2), (2, 2), False), (D, (1, 2), (2, 2), False),
+            (R, (2, 2), (3, 2), False), (R, (2, 2), (3, 2), False), (D, (2, 3), (3, 2), False),
+            (D, (2, 3), (3, 2), False), (R, (3, 3), (3, 2), False), (R, (3, 3), (3, 2), False),
+            (U, (3, 2), (3, 1), True), (U, (3, 2), (3, 1), True)]
+    for a, agent, m0, is_goal in walk:
+        succ, moved, goal = pz.expand4(state)
+        nxt = succ[0, a].cpu().numpy()
+        assert nxt.tolist() == p2d([agent, m0])
+        assert bool(goal[0, a].item()) == is_goal
+        changed = nxt.tolist() != state[0].tolist()
+        assert (int(moved[0, a].item()) != 0) == changed
+        state = nxt[None].astype(np.int32)
+
+    ns = PushWorldPuzzle(os.path.join(CPP, "no_solution.pwp"), order="cpp")
+    order, succ, moved, goal, n = bfs(ns, 10000)
+    assert len(order) == 9 and n == 9 and not goal.any()
+
+    # breadth-first distance to the first goal state of trivial.pwp is 4 and the plan is unique
+    order, succ, moved, goal, n = bfs(pz, 10000)
+    index = {s: i for i, s in enumerate(order)}
+    depth = {0: 0}
+    plans = {0: [""]}
+    for i in range(n):
+        for a in range(4):
+            j = index[tuple(int(v) for v in succ[i, a])]
+            if j not in depth:
+                depth[j] = depth[i] + 1
+                plans[j] = [p + "LRUD"[a] for p in plans[i]]
+            elif depth[j] == depth[i] + 1 and j != i:
+                plans[j] += [p + "LRUD"[a] for p in plans[i]]
+    goal_states = {index[tuple(int(v) for v in succ[i, a])] for i in range(n) for a in range(4) if goal[i, a]}
+    best = min(depth[g] for g in goal_states)
+    assert best == 4
+    assert sorted(p for g in goal_states if depth[g] == best for p in plans[g]) == ["RDRU"]
+
+
+def test_expand_large_frontier_consistency(golden):
+    """>= 100k states of 'level1/2 Obstacle': expand4 agrees with 4 single-action pw_step
+    launches on the same states (two different kernels, same dynamics)."""
+    import torch
+
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    text = golden.text("bench:level1/2 Obstacle.pwp")
+    pz = PushWorldPuzzle(text=text, order="cpp")
+    order, *_ = bfs(pz, 120000)
+    states = np.array(order, dtype=np.int32)
+    F, n = states.shape
+    succ, moved, goal = pz.expand4(states)
+    succ = succ.cpu().numpy()
+    vec = VecPushWorld([pz], F, observation=None, device=0)
+    vec.reset()
+    base = np.zeros((F, vec.num_objects_padded, 2), np.int8)
+    base[:, :n, 0] = states // 10000
+    base[:, :n, 1] = states % 10000
+    for a in range(4):
+        vec.set_states(base)
+        _, _, term, _ = vec.step(torch.full((F,), a, dtype=torch.uint8, device=vec.device))
+        got = vec.states()[:, :n].astype(np.int32)
+        assert (got[:, :, 0] * 10000 + got[:, :, 1] == succ[:, a]).all()
+        assert (term.cpu().numpy() == goal[:, a].cpu().numpy()).all()
