@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--obs", choices=["uint8", "float32", "none"], default="uint8")
     ap.add_argument("--max-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=0, help="1: pw_step_render single launch; 0: pw_step + pw_render")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,10 +127,15 @@ def main():
         if obs_mode is None:
             eng.step(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
                      vec.flags)
-        else:
+        elif args.fused:
             # ONE launch: wave 0 of each workgroup advances its environment, the workgroup draws it
             eng.step_render(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated,
                             vec.truncated, vec._obs_storage, vec.flags)
+        else:
+            # lane-per-env step kernel (a few microseconds) + render kernel on the same stream
+            eng.step(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
+                     vec.flags)
+            eng.render(vec.puzzle_id, vec.pos, vec._obs_storage)
         if events is not None:
             events[1].record()
 
@@ -204,7 +210,7 @@ def main():
                     traffic = None
             out["roofline"] = {
                 "kernel": ("pw_render_u8_ppc3_kernel" if (args.obs == "uint8" and args.ppc == 3 and args.bw == 1)
-                           else "pw_render_generic_kernel") + " (fused step + render)",
+                           else "pw_render_generic_kernel") + (" (fused step + render)" if args.fused else " + pw_step_lane_kernel"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -163,16 +163,44 @@ class ParsedPuzzle:
         gbuf = (c_int32 * (2 * max(g, 1)))()
         check(lib.pw_puzzle_goal_state(h, gbuf))
         self.goal_state = tuple((gbuf[2 * i], gbuf[2 * i + 1]) for i in range(g))
-        self.object_cells = [_cells(lib.pw_puzzle_object_cells, h, j) for j in range(n)]
-        self.goal_cells = [_cells(lib.pw_puzzle_goal_cells, h, k) for k in range(g)]
-        self.wall_cells = _cells(lib.pw_puzzle_wall_cells, h)
-        self.agent_wall_cells = _cells(lib.pw_puzzle_agent_wall_cells, h)
-        names = []
-        for j in range(n):
-            nb = ctypes.create_string_buffer(64)
-            check(lib.pw_puzzle_object_name(h, j, nb, 64))
-            names.append(nb.value.decode())
-        self.names = names
+        self._cache = {}
+
+    # cell lists are only needed by the Python mirrors' properties: fetched on first use so that
+    # loading the 15 400 level-0 puzzles stays cheap
+    def _lazy(self, key, make):
+        if key not in self._cache:
+            self._cache[key] = make()
+        return self._cache[key]
+
+    @property
+    def object_cells(self):
+        return self._lazy("obj", lambda: [_cells(lib.pw_puzzle_object_cells, self.handle, j)
+                                          for j in range(self.num_movables)])
+
+    @property
+    def goal_cells(self):
+        return self._lazy("goal", lambda: [_cells(lib.pw_puzzle_goal_cells, self.handle, k)
+                                           for k in range(self.num_goals)])
+
+    @property
+    def wall_cells(self):
+        return self._lazy("wall", lambda: _cells(lib.pw_puzzle_wall_cells, self.handle))
+
+    @property
+    def agent_wall_cells(self):
+        return self._lazy("aw", lambda: _cells(lib.pw_puzzle_agent_wall_cells, self.handle))
+
+    @property
+    def names(self):
+        def make():
+            out = []
+            for j in range(self.num_movables):
+                nb = ctypes.create_string_buffer(64)
+                check(lib.pw_puzzle_object_name(self.handle, j, nb, 64))
+                out.append(nb.value.decode())
+            return out
+
+        return self._lazy("names", make)
 
     def __del__(self):
         h = getattr(self, "handle", None)

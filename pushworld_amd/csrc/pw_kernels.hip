@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -41,6 +42,7 @@ struct PwEngine {
   int64_t obs_bytes;
   size_t render_lds;
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
+  bool step_wave_kernel;   // pw_step uses the wavefront-per-env kernel instead of lane-per-env
   uint16_t* d_estat;       // per puzzle: static zone-colour table in this engine's frame layout
   uint32_t* d_estat_off;   // byte offset of puzzle p's table in d_estat (16 B aligned)
   uint32_t pal_rgb[16];
@@ -330,6 +332,262 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
   int xy;
   bool legal;
   step_one_env(a, env, lane, pv, xy, legal);
+}
+
+// ------------------------------------------------------------------------------------
+// K1b step, one LANE per environment (state-only batches: configs C2 / C4)
+//
+// Same predicate as the wavefront kernel, evaluated by a single lane on the few rows where two
+// bounding boxes can meet: object rows are fetched from the packed shape rows (L1 hits, the
+// lanes of a wave mostly share a puzzle) instead of being spread over a wave.  64x less
+// ALU work and coalesced per-env outputs; used by pw_step, while the fused step+render launch
+// and pw_expand4 keep the wavefront formulation.
+// ------------------------------------------------------------------------------------
+struct LanePuzzle {
+  const PwPuzzleHeader* h;
+  const uint64_t* wall;
+  const uint64_t* awall;
+  const uint64_t* shapes;
+  int H, N, G;
+};
+
+struct LaneObj {
+  int x, y, w, h, off;
+};
+
+// ot = packed PwObjEntry (w | h << 8 | row_off << 16)
+__device__ __forceinline__ LaneObj lane_obj(uint32_t ot, int xy) {
+  LaneObj o;
+  o.x = static_cast<int8_t>(xy & 0xff);
+  o.y = static_cast<int8_t>((xy >> 8) & 0xff);
+  o.w = static_cast<int>(ot & 0xffu);
+  o.h = static_cast<int>((ot >> 8) & 0xffu);
+  o.off = static_cast<int>(ot >> 16);
+  return o;
+}
+
+// The agent's wall test with every load issued up front (one memory latency instead of one per
+// row): window of 8 grid rows around the agent; taller agents use the generic loop.
+__device__ __forceinline__ bool lane_agent_blocked(const LanePuzzle& p, const LaneObj& o, int act);
+
+// row yy of the board that holds only object o (same conventions as object_row())
+__device__ __forceinline__ uint64_t lane_row(const LanePuzzle& p, const LaneObj& o, int yy) {
+  const int rr = yy - o.y;
+  uint64_t r = 0;
+  if (static_cast<unsigned>(rr) < static_cast<unsigned>(o.h) && static_cast<unsigned>(yy) < 64u) r = p.shapes[o.off + rr];
+  return (static_cast<unsigned>(o.x) < 64u) ? (r << o.x) : 0ull;
+}
+
+// row yy of the board of object o displaced by the action (cf. shift_rows())
+__device__ __forceinline__ uint64_t lane_row_shifted(const LanePuzzle& p, const LaneObj& o, int yy, int act) {
+  if (act == 0) return lane_row(p, o, yy) >> 1;
+  if (act == 1) return lane_row(p, o, yy) << 1;
+  if (act == 2) return yy == 63 ? 0ull : lane_row(p, o, yy + 1);
+  return yy == 0 ? 0ull : lane_row(p, o, yy - 1);
+}
+
+// moving o collides with the static rows and o does not overlap them now (puzzle.py:522-564)
+__device__ __forceinline__ bool lane_blocked(const LanePuzzle& p, const LaneObj& o, const uint64_t* rows, int act) {
+  uint64_t hit = 0, now = 0;
+  for (int yy = o.y - 1; yy <= o.y + o.h; yy++) {
+    if (static_cast<unsigned>(yy) >= static_cast<unsigned>(p.H)) continue;
+    const uint64_t g = rows[yy];
+    hit |= lane_row_shifted(p, o, yy, act) & g;
+    now |= lane_row(p, o, yy) & g;
+  }
+  return hit != 0 && now == 0;
+}
+
+// moving a pushes b: they overlap after the move and do not overlap now (puzzle.py:567-593)
+__device__ __forceinline__ bool lane_pushes(const LanePuzzle& p, const LaneObj& a, const LaneObj& b, int act, int dx,
+                                            int dy) {
+  // bounding boxes of the displaced pusher and of the pushee must meet
+  if (a.x + dx >= b.x + b.w || b.x >= a.x + dx + a.w || a.y + dy >= b.y + b.h || b.y >= a.y + dy + a.h) return false;
+  uint64_t hit = 0, now = 0;
+  for (int yy = b.y; yy < b.y + b.h; yy++) {
+    const uint64_t rb = lane_row(p, b, yy);
+    hit |= lane_row_shifted(p, a, yy, act) & rb;
+    now |= lane_row(p, a, yy) & rb;
+  }
+  return hit != 0 && now == 0;
+}
+
+__device__ __forceinline__ bool lane_agent_blocked(const LanePuzzle& p, const LaneObj& o, int act) {
+  if (o.h > 6) return lane_blocked(p, o, p.awall, act);
+  uint64_t g[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int yy = o.y - 1 + k;
+    g[k] = (static_cast<unsigned>(yy) < static_cast<unsigned>(p.H)) ? p.awall[yy] : 0ull;
+    // sh[k] = board row yy of the agent (k = 0 and k = 7 are outside for h <= 6)
+    const int rr = k - 1;
+    uint64_t r = 0;
+    if (static_cast<unsigned>(rr) < static_cast<unsigned>(o.h) && static_cast<unsigned>(yy) < 64u) r = p.shapes[o.off + rr];
+    sh[k] = (static_cast<unsigned>(o.x) < 64u) ? (r << o.x) : 0ull;
+  }
+  uint64_t hit = 0, now = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int yy = o.y - 1 + k;
+    uint64_t moved;
+    if (act == 0) moved = sh[k] >> 1;
+    else if (act == 1) moved = sh[k] << 1;
+    else if (act == 2) moved = (k < 7 && yy != 63) ? sh[k + 1] : 0ull;
+    else moved = (k > 0 && yy != 0) ? sh[k - 1] : 0ull;
+    hit |= moved & g[k];
+    now |= sh[k] & g[k];
+  }
+  return hit != 0 && now == 0;
+}
+
+template <int NP>
+__device__ __forceinline__ int lane_pos(const uint32_t (&P)[NP / 2], int j) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < NP / 2; k++) v = (k == (j >> 1)) ? P[k] : v;
+  return static_cast<int>((v >> (16 * (j & 1))) & 0xffffu);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void pw_step_lane_kernel(StepArgs a) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= a.batch) return;
+  const int pid = a.puzzle_id[env];
+  const int act = a.actions[env];
+  const int was_done = a.term[env] | a.trunc[env];
+  const int steps_in = a.steps[env];
+  uint32_t* prow = reinterpret_cast<uint32_t*>(a.pos) + static_cast<int64_t>(env) * (NP / 2);
+  uint32_t P[NP / 2];
+  if (NP == 4) {
+    const uint2 v = *reinterpret_cast<const uint2*>(prow);
+    P[0] = v.x;
+    P[1] = v.y;
+  } else {
+#pragma unroll
+    for (int k = 0; k < NP / 8; k++) {
+      const uint4 v = reinterpret_cast<const uint4*>(prow)[k];
+      P[4 * k + 0] = v.x;
+      P[4 * k + 1] = v.y;
+      P[4 * k + 2] = v.z;
+      P[4 * k + 3] = v.w;
+    }
+  }
+  const PwPuzzleHeader* h = a.hdrs + pid;
+  LanePuzzle p;
+  p.h = h;
+  const uint8_t* b = a.blob + h->base;
+  p.wall = reinterpret_cast<const uint64_t*>(b + h->off_wall);
+  p.awall = reinterpret_cast<const uint64_t*>(b + h->off_awall);
+  p.shapes = reinterpret_cast<const uint64_t*>(b + h->off_shapes);
+  p.H = h->H;
+  p.N = h->N;
+  p.G = h->G;
+
+  if ((a.flags & PW_STEP_AUTORESET) && was_done) {
+#pragma unroll
+    for (int k = 0; k < NP / 2; k++) prow[k] = reinterpret_cast<const uint32_t*>(h->init)[k];
+    a.steps[env] = 0;
+    a.term[env] = 0;
+    a.trunc[env] = 0;
+    if (a.reward) a.reward[env] = 0.0;
+    if (a.dgoals) a.dgoals[env] = 0;
+    return;
+  }
+  if (act > 3) {
+    a.term[env] = 0xFF;
+    a.trunc[env] = 0xFF;
+    return;
+  }
+  const int dx = act == 0 ? -1 : (act == 1 ? 1 : 0);
+  const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
+
+  // the whole object table (bounding boxes + shape-row offsets) with wide loads
+  uint32_t OT[NP];
+#pragma unroll
+  for (int k = 0; k < NP / 4; k++) {
+    const uint4 v = reinterpret_cast<const uint4*>(h->objtab)[k];
+    OT[4 * k + 0] = v.x;
+    OT[4 * k + 1] = v.y;
+    OT[4 * k + 2] = v.z;
+    OT[4 * k + 3] = v.w;
+  }
+
+  uint32_t pushed = 0;
+  const LaneObj agent = lane_obj(OT[0], static_cast<int>(P[0] & 0xffffu));
+  if (!lane_agent_blocked(p, agent, act)) {  // puzzle.py:353
+    pushed = 1u;
+    uint32_t frontier = 0;
+    bool blocked = false;
+    // sweep of the agent over all other movables (positions in registers, static indices)
+#pragma unroll
+    for (int j = 1; j < NP; j++) {
+      if (j < p.N && !blocked) {
+        const LaneObj oj = lane_obj(OT[j], static_cast<int>((P[j >> 1] >> (16 * (j & 1))) & 0xffffu));
+        if (lane_pushes(p, agent, oj, act, dx, dy)) {
+          if (lane_blocked(p, oj, p.wall, act)) {
+            blocked = true;  // transitive stopping
+          } else {
+            pushed |= 1u << j;
+            frontier |= 1u << j;
+          }
+        }
+      }
+    }
+    // pushed objects push further objects (about 0.1 % of steps)
+    while (frontier && !blocked) {
+      const int i = __ffs(frontier) - 1;
+      frontier &= frontier - 1;
+      const LaneObj oi = lane_obj(reinterpret_cast<const uint32_t*>(h->objtab)[i], lane_pos<NP>(P, i));
+      for (int j = 1; j < p.N && !blocked; j++) {
+        if ((pushed >> j) & 1u) continue;
+        const LaneObj oj = lane_obj(reinterpret_cast<const uint32_t*>(h->objtab)[j], lane_pos<NP>(P, j));
+        if (lane_pushes(p, oi, oj, act, dx, dy)) {
+          if (lane_blocked(p, oj, p.wall, act)) {
+            blocked = true;
+          } else {
+            pushed |= 1u << j;
+            frontier |= 1u << j;
+          }
+        }
+      }
+    }
+    if (blocked) pushed = 0;
+  }
+
+  // displaced state + goal bookkeeping (puzzle.py:384-411)
+  int before = 0, after = 0;
+#pragma unroll
+  for (int j = 0; j < NP; j++) {
+    const uint32_t sh = 16 * (j & 1);
+    const uint32_t cur = (P[j >> 1] >> sh) & 0xffffu;
+    uint32_t nxt = cur;
+    if ((pushed >> j) & 1u) {
+      const int x = static_cast<int8_t>(cur & 0xff) + dx, y = static_cast<int8_t>((cur >> 8) & 0xff) + dy;
+      nxt = static_cast<uint32_t>(x & 0xff) | (static_cast<uint32_t>(y & 0xff) << 8);
+      P[j >> 1] = (P[j >> 1] & ~(0xffffu << sh)) | (nxt << sh);
+    }
+    if (j >= 1 && j <= p.G) {
+      const uint32_t g = reinterpret_cast<const uint16_t*>(h->goal)[j - 1];
+      before += cur == g;
+      after += nxt == g;
+    }
+  }
+  if (pushed) {
+    if (NP == 4) {
+      *reinterpret_cast<uint2*>(prow) = make_uint2(P[0], P[1]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP / 8; k++)
+        reinterpret_cast<uint4*>(prow)[k] = make_uint4(P[4 * k], P[4 * k + 1], P[4 * k + 2], P[4 * k + 3]);
+    }
+  }
+  const bool terminated = after == p.G;
+  const int s = steps_in + 1;
+  a.steps[env] = s;
+  a.term[env] = terminated ? 1 : 0;
+  a.trunc[env] = (a.max_steps > 0 && s >= a.max_steps) ? 1 : 0;
+  if (a.reward) a.reward[env] = terminated ? 10.0 : static_cast<double>(after - before) - 0.01;
+  if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(after - before);
 }
 
 // ------------------------------------------------------------------------------------
@@ -721,6 +979,10 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   e->fast_u8_ppc3 = cfg->obs_dtype == PW_OBS_U8 && cfg->pixels_per_cell == 3 && cfg->border_width == 1;
   e->d_estat = nullptr;
   e->d_estat_off = nullptr;
+  {
+    const char* sel = getenv("PUSHWORLD_AMD_STEP");
+    e->step_wave_kernel = sel && std::string(sel) == "wave";
+  }
   // Static zone-colour tables (walls, agent walls, background, goal outlines) of every puzzle in
   // the layout the render kernel of this engine streams from: row stride pad_w with the puzzle
   // shifted by c0 virtual columns for the 3-pixel fast path, row stride W otherwise.
@@ -849,8 +1111,18 @@ int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_
   int rc = fill_step_args(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, batch, flags, &a);
   if (rc != PW_OK) return rc;
   if (batch <= 0) return PW_OK;
-  const unsigned blocks = static_cast<unsigned>((batch + 3) / 4);
-  hipLaunchKernelGGL(pw_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (e->step_wave_kernel) {  // PUSHWORLD_AMD_STEP=wave: one wavefront per environment
+    hipLaunchKernelGGL(pw_step_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0, st, a);
+    return check_launch("pw_step");
+  }
+  const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
+  switch (e->np) {
+    case 4: hipLaunchKernelGGL(pw_step_lane_kernel<4>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(pw_step_lane_kernel<8>, grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL(pw_step_lane_kernel<16>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(pw_step_lane_kernel<32>, grid, block, 0, st, a); break;
+  }
   return check_launch("pw_step");
 }
 

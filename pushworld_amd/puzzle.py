@@ -104,27 +104,7 @@ class PushWorldPuzzle:
         self.num_movables = p.num_movables
         self._initial_state: State = p.initial_state
         self._goal_state = p.goal_state
-        self._wall_positions = set(p.wall_cells)
-        # trap T2: the reference property returns AW u W (puzzle.py:253,273,338-341)
-        self._agent_wall_positions = set(p.agent_wall_cells) | self._wall_positions
-        g = p.num_goals
-        self._movable_objects = []
-        for j in range(p.num_movables):
-            if j == 0:
-                fill, border = Colors.AGENT, Colors.AGENT_BORDER
-            elif j <= g:
-                fill, border = Colors.GOAL_OBJECT, Colors.GOAL_OBJECT_BORDER
-            else:
-                fill, border = Colors.MOVABLE, Colors.MOVABLE_BORDER
-            self._movable_objects.append(
-                PushWorldObject(position=p.initial_state[j], fill_color=fill, border_color=border,
-                                cells=set(p.object_cells[j]))
-            )
-        self._goals = [
-            PushWorldObject(position=p.goal_state[k], fill_color=Colors.GOAL, border_color=Colors.GOAL_BORDER,
-                            cells=set(p.goal_cells[k]))
-            for k in range(g)
-        ]
+        self._lazy_props = {}
         self._pset = None
         self._engines = {}
         self._bufs = None
@@ -142,17 +122,43 @@ class PushWorldPuzzle:
     def dimensions(self) -> Tuple[int, int]:
         return (self._width, self._height)
 
+    def _prop(self, key, make):
+        if key not in self._lazy_props:
+            self._lazy_props[key] = make()
+        return self._lazy_props[key]
+
     @property
     def wall_positions(self) -> Set[Point]:
-        return self._wall_positions
+        return self._prop("wall", lambda: set(self._parsed.wall_cells))
 
     @property
     def agent_wall_positions(self) -> Set[Point]:
-        return self._agent_wall_positions
+        # trap T2: the reference property returns AW u W (puzzle.py:253,273,338-341)
+        return self._prop("aw", lambda: set(self._parsed.agent_wall_cells) | self.wall_positions)
 
     @property
     def movable_objects(self) -> List[PushWorldObject]:
-        return self._movable_objects
+        def make():
+            p, g, out = self._parsed, self._parsed.num_goals, []
+            for j in range(p.num_movables):
+                if j == 0:
+                    fill, border = Colors.AGENT, Colors.AGENT_BORDER
+                elif j <= g:
+                    fill, border = Colors.GOAL_OBJECT, Colors.GOAL_OBJECT_BORDER
+                else:
+                    fill, border = Colors.MOVABLE, Colors.MOVABLE_BORDER
+                out.append(PushWorldObject(position=p.initial_state[j], fill_color=fill, border_color=border,
+                                           cells=set(p.object_cells[j])))
+            return out
+
+        return self._prop("movables", make)
+
+    @property
+    def _goals(self) -> List[PushWorldObject]:
+        p = self._parsed
+        return self._prop("goals", lambda: [
+            PushWorldObject(position=p.goal_state[k], fill_color=Colors.GOAL, border_color=Colors.GOAL_BORDER,
+                            cells=set(p.goal_cells[k])) for k in range(p.num_goals)])
 
     # ---------------------------------------------------------------- device plumbing
     def _puzzle_set(self) -> "_capi.PuzzleSet":

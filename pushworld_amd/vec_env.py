@@ -33,13 +33,15 @@ class VecPushWorld:
         pad_cells: (height, width) of the observation frame in cells; default = pool maximum
             (gym_env.py:80-82).
         autoreset: next-step autoreset inside the step kernel.
+        fused: step and render in ONE launch (``pw_step_render``) instead of the lane-per-env step
+            kernel followed by the render kernel.
     """
 
     def __init__(self, puzzles: Sequence[Union[str, PushWorldPuzzle]], num_envs: int,
                  puzzle_ids: Optional[Sequence[int]] = None, max_steps: Optional[int] = None,
                  border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
-                 autoreset: bool = False):
+                 autoreset: bool = False, fused: bool = False):
         self.puzzles = [p if isinstance(p, PushWorldPuzzle) else PushWorldPuzzle(p) for p in puzzles]
         if not self.puzzles:
             raise ValueError("No PushWorld puzzles given")
@@ -54,6 +56,7 @@ class VecPushWorld:
         self.num_envs = int(num_envs)
         self.observation = observation
         self.flags = _capi.STEP_AUTORESET if autoreset else 0
+        self.fused = bool(fused)
 
         if puzzle_ids is None:
             ids = np.arange(self.num_envs) % len(self.puzzles)
@@ -103,12 +106,14 @@ class VecPushWorld:
             raise RuntimeError("reset() must be called before step() can be called.")
         if actions.dtype != torch.uint8 or actions.device != self.device or actions.shape != (self.num_envs,):
             raise ValueError("actions must be a uint8 tensor of shape [num_envs] on the engine's device")
-        if self.obs is not None:
+        if self.obs is not None and self.fused:
             self.engine.step_render(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
                                     self.terminated, self.truncated, self._obs_storage, self.flags)
         else:
             self.engine.step(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
                              self.terminated, self.truncated, self.flags)
+            if self.obs is not None:
+                self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
         return self.obs, self.reward, self.terminated, self.truncated
 
     def render(self):

@@ -1,0 +1,200 @@
+"""-m gpu: the BASELINE.json configurations as parity / property tests.
+
+C1 single level-0 puzzle through the gym adapter; C2 4 096 copies of one level-0 puzzle,
+state only; C3 65 536 Level-1 envs with render (bench workload, checked here on samples and
+through size-independent properties); C4 one rank's shard (65 536 envs) of the full mix
+levels 0-4."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _l0_text(golden, member="level0/base/train/level_0_base_train_0.pwp"):
+    return golden.text("l0:" + member)
+
+
+def test_c1_single_env_gym_adapter(golden, tmp_path):
+    """C1: one level-0 puzzle, batch 1, default render (ppc 20, float32): 2 000 random steps
+    (`numpy.random.default_rng(0)`), reset on termination; every state, reward and flag equals
+    the oracle; observations are compared every 100 steps."""
+    from oracle import pw_oracle
+    from pushworld_amd.gym_env import PushWorldEnv
+
+    text = _l0_text(golden)
+    f = tmp_path / "c1.pwp"
+    f.write_text(text)
+    env = PushWorldEnv(str(f), max_steps=60)
+    oz = pw_oracle.OraclePuzzle(text)
+    oenv = pw_oracle.OracleEnv(oz, max_steps=60)
+    rng = np.random.default_rng(0)
+    obs, info = env.reset()
+    ostate = oenv.reset()
+    assert info["puzzle_state"] == ostate
+    for t in range(2000):
+        a = int(rng.integers(0, 4))
+        obs, r, term, trunc, info = env.step(a)
+        ostate, orew, oterm, otrunc = oenv.step(a)
+        assert info["puzzle_state"] == ostate and r == orew and term == oterm and trunc == otrunc
+        if t % 100 == 0:
+            assert (obs == oz.observation(ostate, oz.height, oz.width)).all()
+        if term or trunc:
+            env.reset()
+            oenv.reset()
+
+
+def test_c2_4096_copies_state_only(golden):
+    """C2: 4 096 copies of one level-0 puzzle, state only, max_steps 100 with autoreset: copies
+    driven by the same actions stay identical and equal the oracle; copies driven by different
+    actions are checked individually on a sample."""
+    import torch
+
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    text = _l0_text(golden)
+    pz = PushWorldPuzzle(text=text)
+    oz = c_oracle.COraclePuzzle(text)
+    B, T = 4096, 400
+    vec = VecPushWorld([pz], B, max_steps=100, observation=None, device=0, autoreset=True)
+    vec.reset()
+    gen = torch.Generator(device=vec.device)
+    gen.manual_seed(0)
+    acts = torch.randint(0, 4, (T, B), generator=gen, device=vec.device, dtype=torch.uint8)
+    acts[:, : B // 2] = acts[:, :1]  # first half: identical action streams
+    acts_h = acts.cpu().numpy()
+    sample = [0, 1, B // 2 - 1, B // 2, B // 2 + 17, B - 1]
+    states = {b: oz.initial_state for b in sample}
+    steps = {b: 0 for b in sample}
+    done = {b: False for b in sample}
+    for t in range(T):
+        _, r, te, tr = vec.step(acts[t])
+        pos = vec.states()
+        rr, tt, uu = r.cpu().numpy(), te.cpu().numpy(), tr.cpu().numpy()
+        assert (pos[: B // 2] == pos[0]).all() and (rr[: B // 2] == rr[0]).all()
+        for b in sample:
+            if done[b]:  # next-step autoreset
+                states[b], steps[b], done[b] = oz.initial_state, 0, False
+                want = (states[b], 0.0, False, False)
+            else:
+                s, rew, term = oz.env_step(states[b], int(acts_h[t, b]))
+                steps[b] += 1
+                trunc = steps[b] >= 100
+                states[b], done[b] = s, term or trunc
+                want = (s, rew, term, trunc)
+            assert tuple(map(tuple, pos[b, : oz.num_movables].tolist())) == want[0], (t, b)
+            assert rr[b] == want[1] and bool(tt[b]) == want[2] and bool(uu[b]) == want[3], (t, b)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_c3_level1_mix_full_batch(golden, fused):
+    """C3 at the bench's full size (65 536 envs, 68 Level-1 puzzles, frame 51x42, uint8 ppc 3):
+    sampled envs equal the oracle (state, reward, flags, full observation); all envs satisfy the
+    size-independent properties: envs of one puzzle with equal action histories are identical;
+    the observation is a pure function of (puzzle, state) [re-render == step output];
+    padding bytes are zero; step counters advance by one."""
+    import torch
+
+    import bench
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    B, T = 65536, 12
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, pixels_per_cell=3,
+                       border_width=1, observation="uint8", device=0, autoreset=True, fused=fused)
+    assert vec.engine.obs_shape == (153, 126, 3)
+    vec.reset()
+    gen = torch.Generator(device=vec.device)
+    gen.manual_seed(1)
+    acts = torch.randint(0, 4, (T, B), generator=gen, device=vec.device, dtype=torch.uint8)
+    acts[:, 1::2] = acts[:, 0::2]  # neighbours (same puzzle except at group borders) share actions
+    acts_h = acts.cpu().numpy()
+    sample = list(range(0, B, 1543)) + [B - 1]
+    oracles = {}
+    for b in sample:
+        if ids[b] not in oracles:
+            with open(paths[ids[b]]) as f:
+                oracles[ids[b]] = c_oracle.COraclePuzzle(f.read())
+    states = {b: oracles[ids[b]].initial_state for b in sample}
+    for t in range(T):
+        obs, r, te, tr = vec.step(acts[t])
+        pos = vec.states()
+        same = ids[0::2] == ids[1::2]
+        assert (pos[0::2][same] == pos[1::2][same]).all()
+        assert (vec.steps.cpu().numpy() == t + 1).all()
+        rr, tt = r.cpu().numpy(), te.cpu().numpy()
+        for b in sample:
+            oz = oracles[ids[b]]
+            s, rew, term = oz.env_step(states[b], int(acts_h[t, b]))
+            states[b] = s
+            assert tuple(map(tuple, pos[b, : oz.num_movables].tolist())) == s and rr[b] == rew and bool(tt[b]) == term
+        if t in (0, T - 1):
+            first = obs.clone()
+            again = vec.render()
+            assert torch.equal(first, again)
+            for b in sample[::4]:
+                oz = oracles[ids[b]]
+                assert (obs[b].cpu().numpy() == oz.observation(states[b], 51, 42, 3, 1, dtype="u8")).all(), b
+            # zero padding around every puzzle smaller than the frame (env_utils.py:75-91)
+            b = sample[3]
+            oz = oracles[ids[b]]
+            top = (153 - oz.height * 3) // 2
+            left = (126 - oz.width * 3) // 2
+            img = obs[b].cpu().numpy()
+            assert img[:top].sum() == 0 and img[:, :left].sum() == 0
+            assert img[top + oz.height * 3:].sum() == 0 and img[:, left + oz.width * 3:].sum() == 0
+
+
+def test_c4_full_mix_shard(golden):
+    """C4, one rank's shard: 65 536 envs, 50 % level 0 (7 families, train) + 50 % levels 1-4
+    (223 puzzles), frame 54x47, NP 32, state-only headline + uint8 ppc 3 render variant.
+    Sampled envs equal the oracle over a random walk; observations of sampled envs equal the
+    oracle's padded image."""
+    import torch
+
+    from oracle import c_oracle
+    from pushworld_amd.benchmark_data import level0_texts, level_paths
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    l0 = level0_texts(limit=300)  # 7 x 300 level-0 puzzles
+    texts = list(l0.values())
+    for lv in (1, 2, 3, 4):
+        for p in level_paths(lv):
+            with open(p) as f:
+                texts.append(f.read())
+    n0 = len(l0)
+    pool = [PushWorldPuzzle(text=t) for t in texts]
+    B, T = 65536, 40
+    rng = np.random.default_rng(100)
+    ids = np.concatenate([rng.integers(0, n0, B // 2), rng.integers(n0, len(pool), B // 2)])
+    ids.sort()
+    vec = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=None, pixels_per_cell=3, border_width=1,
+                       observation="uint8", pad_cells=(54, 47), device=0)
+    assert vec.num_objects_padded == 32 and vec.engine.obs_shape == (162, 141, 3)
+    vec.reset()
+    gen = torch.Generator(device=vec.device)
+    gen.manual_seed(100)
+    acts = torch.randint(0, 4, (T, B), generator=gen, device=vec.device, dtype=torch.uint8)
+    acts_h = acts.cpu().numpy()
+    sample = list(range(0, B, 997))
+    oracles = {i: c_oracle.COraclePuzzle(texts[i]) for i in {int(ids[b]) for b in sample}}
+    states = {b: oracles[int(ids[b])].initial_state for b in sample}
+    for t in range(T):
+        obs, r, te, tr = vec.step(acts[t])
+        if t % 13 and t != T - 1:
+            for b in sample:
+                states[b] = oracles[int(ids[b])].env_step(states[b], int(acts_h[t, b]))[0]
+            continue
+        pos, rr, tt = vec.states(), r.cpu().numpy(), te.cpu().numpy()
+        for k, b in enumerate(sample):
+            oz = oracles[int(ids[b])]
+            s, rew, term = oz.env_step(states[b], int(acts_h[t, b]))
+            states[b] = s
+            assert tuple(map(tuple, pos[b, : oz.num_movables].tolist())) == s and rr[b] == rew and bool(tt[b]) == term
+            if k % 8 == 0:
+                assert (obs[b].cpu().numpy() == oz.observation(s, 54, 47, 3, 1, dtype="u8")).all(), (t, b)

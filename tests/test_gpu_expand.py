@@ -46,7 +46,7 @@ def bfs(puzzle, max_states):
     "cpptest:blocked_transitive_pushing1.pwp", "cpptest:blocked_transitive_pushing2.pwp",
     "cpptest:necessary_transitive_pushing3.pwp", "cpptest:multiple_goals.pwp", "cpptest:file_parsing.pwp",
     "bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp", "bench:level4/Four Pistons.pwp",
-    "bench:level1/Pulling.pwp", "bench:level3/Jump In The Tetris Line.pwp",
+    "bench:level1/Pulling.pwp", "bench:level3/Armor.pwp",
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle

@@ -40,11 +40,14 @@ def _groups(golden):
     return g
 
 
-@pytest.mark.parametrize("group", ["bench", "tests", "l0"])
-def test_trajectories_match_reference(golden, puzzles, torch_mod, group):
+@pytest.mark.parametrize("group,kernel", [("bench", "lane"), ("tests", "lane"), ("l0", "lane"),
+                                          ("bench", "wave"), ("tests", "wave")])
+def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
-    one mixed batch: positions, float64 reward bits, terminated, truncated, step counter."""
+    one mixed batch: positions, float64 reward bits, terminated, truncated, step counter.
+    pw_step has two kernels (one lane per env / one wavefront per env); both are checked."""
     torch = torch_mod
+    monkeypatch.setenv("PUSHWORLD_AMD_STEP", kernel)
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = _groups(golden)[group]
@@ -95,10 +98,12 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group):
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-def test_random_overlapping_states(golden, puzzles, torch_mod):
+@pytest.mark.parametrize("kernel", ["lane", "wave"])
+def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
     torch = torch_mod
+    monkeypatch.setenv("PUSHWORLD_AMD_STEP", kernel)
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = [k for k in golden.keys if f"{k}|in" in golden.states]
@@ -205,7 +210,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod):
     B = len(envs)
     T = 120
     vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=None, pixels_per_cell=3, border_width=1,
-                       observation="uint8", device=0)
+                       observation="uint8", device=0, fused=True)
     obs0 = vec.reset()
     oracles = {k: c_oracle.COraclePuzzle(golden.text(k)) for k in keys}
     fh, fw = vec.engine.obs_shape[0] // 3, vec.engine.obs_shape[1] // 3
