@@ -43,6 +43,8 @@ struct PwEngine {
   size_t render_lds;
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
   bool step_wave_kernel;   // pw_step uses the wavefront-per-env kernel instead of lane-per-env
+  uint8_t* d_simg;         // per puzzle: observation of the static layers only (copy+patch render path)
+  int64_t simg_stride;     // bytes between the static images of consecutive puzzles
   uint16_t* d_estat;       // per puzzle: static zone-colour table in this engine's frame layout
   uint32_t* d_estat_off;   // byte offset of puzzle p's table in d_estat (16 B aligned)
   uint32_t pal_rgb[16];
@@ -663,8 +665,11 @@ struct RenderArgs {
   uint32_t pal_rgb[16];    // byte0 = R, byte1 = G, byte2 = B
   float pal_f32[16][4];    // uint8 -> float32 / 255 (env_utils.py:65-72), exact IEEE division
   int32_t do_step;         // fused pw_step_render: wave 0 advances the environment first
+  int32_t skip_movables;   // draw the static layers only (engine setup: static images)
   StepArgs step;
 };
+
+static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipStream_t st);
 
 // LDS layout of the render kernels (dynamic):
 //   [0, 16)        8 zero guard entries in front of E
@@ -736,6 +741,7 @@ __device__ __forceinline__ void build_zone_table(const RenderArgs& a, const Puzz
     if (lane == 0) l.flag[0] = legal ? 1u : 0u;
   }
   __syncthreads();
+  if (a.skip_movables) return;
   if (l.flag[0]) {
     for (int m = tid; m < pv.n_mcells; m += blockDim.x) patch_cell(pv, l.E, l.spos, pv.mcells[m], estride, c0);
   } else {
@@ -818,6 +824,179 @@ __global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_u8_ppc3_kernel(Re
     v.z = __builtin_amdgcn_alignbyte(s3, s2, bs);
     v.w = __builtin_amdgcn_alignbyte(s4, s3, bs);
     *reinterpret_cast<uint4*>(out + static_cast<int64_t>(chunk) * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Copy + patch render path (uint8, ppc 3): the observation of a state differs from the
+// observation of the puzzle's static layers only under the movables (1.2 % of the bytes on the
+// Level-1 mix), and HBM takes ~25 % more write bandwidth when the whole chip sweeps 4 KiB
+// pages in address order (profiles/r01_store_pattern.txt).  So:
+//   pass 1  pw_render_copy_kernel   short-lived workgroups, one 4 KiB page of the obs buffer each,
+//                                   in address order: L2-resident static image -> HBM
+//   pass 2  pw_render_patch_kernel  one wavefront per environment draws the 9-byte pixel triples
+//                                   of the cells under the movables over it
+// ------------------------------------------------------------------------------------
+struct CopyArgs {
+  const uint8_t* simg;
+  const int32_t* puzzle_id;
+  uint8_t* obs;
+  int64_t simg_stride;
+  int32_t batch;
+  uint32_t chunks_per_env;  // env stride / 16
+  uint32_t n_chunks;        // 16-byte chunks of one observation
+};
+
+#ifndef PW_COPY_THREADS
+#define PW_COPY_THREADS 64  // workgroup = one 4 KiB page = one wavefront; each lane moves 4 chunks
+#endif
+__global__ __launch_bounds__(PW_COPY_THREADS) void pw_render_copy_kernel(CopyArgs a) {
+  constexpr int kPerThread = 256 / PW_COPY_THREADS;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  // The page holds chunks [g0, g0 + 256) of at most two environments: their puzzle ids are
+  // workgroup-uniform (scalar loads), so a lane's only dependent access is the image load.
+  const uint32_t g0 = blockIdx.x * 256u;
+  const uint32_t env0 = g0 / a.chunks_per_env;
+  const uint32_t last = static_cast<uint32_t>(a.batch) - 1u;
+  const int pid0 = a.puzzle_id[min(env0, last)];
+  const int pid1 = a.puzzle_id[min(env0 + 1u, last)];
+  const uint32_t split = (env0 + 1u) * a.chunks_per_env;  // first chunk of the next environment
+  u32x4 v[kPerThread];
+  bool ok[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; k++) {
+    const uint32_t g = g0 + threadIdx.x + k * PW_COPY_THREADS;
+    const bool second = g >= split;
+    const uint32_t env = second ? env0 + 1u : env0;
+    const uint32_t c = g - env * a.chunks_per_env;
+    ok[k] = env <= last && c < a.n_chunks;
+    const int pid = second ? pid1 : pid0;
+    const uint8_t* src = a.simg + static_cast<int64_t>(pid) * a.simg_stride + static_cast<int64_t>(c) * 16;
+    if (ok[k]) v[k] = *reinterpret_cast<const u32x4*>(src);
+  }
+#pragma unroll
+  for (int k = 0; k < kPerThread; k++) {
+    const uint32_t g = g0 + threadIdx.x + k * PW_COPY_THREADS;
+    uint8_t* dst = a.obs + static_cast<int64_t>(g) * 16;
+    // streaming (nt) store: the 3.8 GB output stream should not displace the static images the
+    // loads are served from
+#if defined(PW_COPY_PLAIN_STORE)
+    if (ok[k]) *reinterpret_cast<u32x4*>(dst) = v[k];
+#elif defined(PW_COPY_SC1_STORE)
+    if (ok[k]) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v[k]) : "memory");
+#else
+    if (ok[k]) __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(dst));  // measured best (profiles/)
+#endif
+  }
+}
+
+__device__ __forceinline__ void draw_cell_ppc3(const uint32_t* pal, int W, int H, int G, int pad_w, const uint16_t* estat,
+                                               uint8_t* out, uint32_t c, int p, int c0, int shift_bytes) {
+  const int obj = c >> 24;
+  const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
+  const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
+  if (static_cast<unsigned>(x) >= static_cast<unsigned>(W) || static_cast<unsigned>(y) >= static_cast<unsigned>(H)) return;
+  const uint32_t kind = obj == 0 ? 3u : (obj <= G ? 4u : 5u);
+  const uint32_t om = (c >> 16) & 0xffu;
+  const int q0 = 3 * y * pad_w + x + c0;
+  uint32_t se[3];
+#pragma unroll
+  for (int zy = 0; zy < 3; zy++) se[zy] = estat[q0 + zy * pad_w];
+#pragma unroll
+  for (int zy = 0; zy < 3; zy++) {
+    const uint32_t e = pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_entry_goal_bits(se[zy]));
+    const uint32_t r0 = pal[e & 15u], r1 = pal[(e >> 4) & 15u], r2 = pal[(e >> 8) & 15u];
+    uint8_t* d = out + (9 * (q0 + zy * pad_w) + shift_bytes);
+    const uint32_t w0 = r0 | (r1 << 24), w1 = (r1 >> 8) | (r2 << 16), w2 = r2 >> 16;  // 9 bytes
+    if (reinterpret_cast<uintptr_t>(d) & 1) {
+      d[0] = static_cast<uint8_t>(w0);
+      *reinterpret_cast<uint16_t*>(d + 1) = static_cast<uint16_t>(w0 >> 8);
+      *reinterpret_cast<uint16_t*>(d + 3) = static_cast<uint16_t>((w0 >> 24) | (w1 << 8));
+      *reinterpret_cast<uint16_t*>(d + 5) = static_cast<uint16_t>(w1 >> 8);
+      *reinterpret_cast<uint16_t*>(d + 7) = static_cast<uint16_t>((w1 >> 24) | (w2 << 8));
+    } else {
+      *reinterpret_cast<uint16_t*>(d) = static_cast<uint16_t>(w0);
+      *reinterpret_cast<uint16_t*>(d + 2) = static_cast<uint16_t>(w0 >> 16);
+      *reinterpret_cast<uint16_t*>(d + 4) = static_cast<uint16_t>(w1);
+      *reinterpret_cast<uint16_t*>(d + 6) = static_cast<uint16_t>(w1 >> 16);
+      d[8] = static_cast<uint8_t>(w2);
+    }
+  }
+}
+
+// GS lanes per environment (GS = 16 when the padded object count is <= 16, else 32): lane l of a
+// group holds object l's position and bounding box, and draws cell m0 + l of the movable-cell list.
+template <int GS>
+__global__ __launch_bounds__(256) void pw_render_patch_kernel(RenderArgs a) {
+  __shared__ uint32_t pal[16];
+  if (threadIdx.x < 16) pal[threadIdx.x] = a.pal_rgb[threadIdx.x];
+  __syncthreads();
+  constexpr int kGroups = 256 / GS;
+  const int lane = threadIdx.x & (PW_WAVE - 1);
+  const int lj = threadIdx.x & (GS - 1);          // lane within the group
+  const int gbase = lane & ~(GS - 1);             // first lane of the group inside the wave
+  const int env = blockIdx.x * kGroups + static_cast<int>(threadIdx.x) / GS;
+  const bool live = env < a.batch;
+  const int pid = live ? a.puzzle_id[env] : 0;
+  const PwPuzzleHeader* h = a.hdrs + pid;
+  const int W = h->W, H = h->H, N = live ? h->N : 0, G = h->G;
+  const int n_mcells = live ? static_cast<int>(h->n_mcells) : 0;
+  const uint32_t* mcells = reinterpret_cast<const uint32_t*>(a.blob + h->base + h->off_mcells);
+
+  int xy = 0;
+  uint32_t ot = 0;
+  if (live && lj < N) {
+    xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + lj]);
+    ot = reinterpret_cast<const uint32_t*>(h->objtab)[lj];
+  }
+  // Conservative overlap test: do the bounding boxes of two movables intersect?  If none do, no
+  // two movables share a cell and all cells can be drawn at once; otherwise the objects are drawn
+  // one after the other so that a higher index wins (puzzle.py:457).
+  const int bx0 = static_cast<int8_t>(xy & 0xff), by0 = static_cast<int8_t>((xy >> 8) & 0xff);
+  const int bx1 = bx0 + static_cast<int>(ot & 0xffu), by1 = by0 + static_cast<int>((ot >> 8) & 0xffu);
+  const int nmax = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, N));
+  bool touch = false;
+  for (int k = 1; k < nmax; k++) {
+    const int partner = (lj + k < N) ? lj + k : lj + k - N;  // (lj + k) mod N for k < N
+    const int src = gbase + (k < N ? partner : lj);
+    const int oxy = __shfl(xy, src, PW_WAVE);
+    const uint32_t oot = static_cast<uint32_t>(__shfl(static_cast<int>(ot), src, PW_WAVE));
+    const int ox0 = static_cast<int8_t>(oxy & 0xff), oy0 = static_cast<int8_t>((oxy >> 8) & 0xff);
+    const int ox1 = ox0 + static_cast<int>(oot & 0xffu), oy1 = oy0 + static_cast<int>((oot >> 8) & 0xffu);
+    if (lj < N && k < N && bx0 < ox1 && ox0 < bx1 && by0 < oy1 && oy0 < by1) touch = true;
+  }
+  const unsigned long long tmask = __ballot(touch);
+  const bool ordered = ((tmask >> gbase) & ((1ull << GS) - 1ull)) != 0ull;
+
+  const int wpx = a.pad_w * 3;
+  const int pady = (a.pad_h - H) * 3 / 2;
+  const int padx = (a.pad_w - W) * 3 / 2;
+  const int c0 = (padx + 2) / 3;
+  const int shift_bytes = 3 * (pady * wpx + padx - 3 * c0);
+  const uint16_t* estat = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[pid]);
+  uint8_t* out = a.obs + static_cast<int64_t>(env) * a.env_stride;
+
+  const int cmax = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, n_mcells));
+  const bool any_ordered = __ballot(ordered) != 0ull;
+  // pass over the cell list; groups that need painter order only draw the agent here
+  for (int m0 = 0; m0 < cmax; m0 += GS) {
+    const int m = m0 + lj;
+    const uint32_t c = m < n_mcells ? mcells[m] : 0u;
+    const int p = __shfl(xy, gbase + static_cast<int>(c >> 24), PW_WAVE);
+    if (m < n_mcells && (!ordered || (c >> 24) == 0u))
+      draw_cell_ppc3(pal, W, H, G, a.pad_w, estat, out, c, p, c0, shift_bytes);
+  }
+  if (any_ordered) {
+    for (int j = 1; j < nmax; j++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // object j - 1 is in L2 before object j is drawn
+      for (int m0 = 0; m0 < cmax; m0 += GS) {
+        const int m = m0 + lj;
+        const uint32_t c = m < n_mcells ? mcells[m] : 0u;
+        const int p = __shfl(xy, gbase + static_cast<int>(c >> 24), PW_WAVE);
+        if (ordered && m < n_mcells && static_cast<int>(c >> 24) == j)
+          draw_cell_ppc3(pal, W, H, G, a.pad_w, estat, out, c, p, c0, shift_bytes);
+      }
+    }
   }
 }
 
@@ -939,6 +1118,7 @@ int fill_render_args(const PwEngine* e, const int32_t* puzzle_id, const int8_t* 
   ra->estat_off = e->d_estat_off;
   ra->obs_bytes = static_cast<int32_t>(e->obs_bytes);
   ra->do_step = 0;
+  ra->skip_movables = 0;
   for (int i = 0; i < 16; i++) {
     ra->pal_rgb[i] = e->pal_rgb[i];
     for (int c = 0; c < 4; c++) ra->pal_f32[i][c] = e->pal_f32[i][c];
@@ -1040,6 +1220,39 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_generic_kernel<float>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
+  // copy+patch render path: static images of all puzzles, drawn once by the LDS kernel itself
+  e->d_simg = nullptr;
+  e->simg_stride = (e->obs_bytes + 255) & ~int64_t(255);
+  const char* rsel = getenv("PUSHWORLD_AMD_RENDER");
+  const bool want_copy = e->fast_u8_ppc3 && !(rsel && std::string(rsel) == "lds") &&
+                         static_cast<int64_t>(s->count) * e->simg_stride <= (int64_t(64) << 20);
+  if (err == hipSuccess && want_copy) {
+    int32_t* d_ids = nullptr;
+    int8_t* d_pos = nullptr;
+    std::vector<int32_t> ids(s->count);
+    for (int p = 0; p < s->count; p++) ids[p] = p;
+    err = hipMalloc(reinterpret_cast<void**>(&e->d_simg), static_cast<size_t>(s->count) * e->simg_stride);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&d_ids), ids.size() * 4);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&d_pos), static_cast<size_t>(s->count) * e->np * 2);
+    if (err == hipSuccess) err = hipMemcpy(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemset(d_pos, 0, static_cast<size_t>(s->count) * e->np * 2);
+    if (err == hipSuccess) {
+      RenderArgs ra;
+      uint8_t* simg = e->d_simg;
+      e->d_simg = nullptr;  // fill_render_args / launch_render must take the LDS path here
+      if (fill_render_args(e, d_ids, d_pos, simg, e->simg_stride, s->count, &ra) == PW_OK) {
+        ra.skip_movables = 1;
+        launch_render(e, ra, s->count, nullptr);
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+      } else {
+        err = hipErrorInvalidValue;
+      }
+      e->d_simg = simg;
+    }
+    if (d_ids) (void)hipFree(d_ids);
+    if (d_pos) (void)hipFree(d_pos);
+  }
   if (err != hipSuccess) {
     std::string msg = std::string("engine setup failed: ") + hipGetErrorString(err);
     pw_engine_destroy(e);
@@ -1053,6 +1266,7 @@ void pw_engine_destroy(PwEngine* e) {
   if (!e) return;
   if (e->d_estat) (void)hipFree(e->d_estat);
   if (e->d_estat_off) (void)hipFree(e->d_estat_off);
+  if (e->d_simg) (void)hipFree(e->d_simg);
   delete e;
 }
 
@@ -1095,6 +1309,23 @@ static int fill_step_args(PwEngine* e, const int32_t* puzzle_id, const uint8_t* 
 }
 
 static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipStream_t st) {
+  if (e->d_simg && !ra.do_step && !ra.skip_movables) {
+    CopyArgs ca;
+    ca.simg = e->d_simg;
+    ca.puzzle_id = ra.puzzle_id;
+    ca.obs = ra.obs;
+    ca.simg_stride = e->simg_stride;
+    ca.batch = batch;
+    ca.chunks_per_env = static_cast<uint32_t>(ra.env_stride / 16);
+    ca.n_chunks = static_cast<uint32_t>((e->obs_bytes + 15) / 16);
+    const uint64_t total = static_cast<uint64_t>(batch) * ca.chunks_per_env;
+    hipLaunchKernelGGL(pw_render_copy_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(PW_COPY_THREADS), 0, st, ca);
+    if (e->np <= 16)
+      hipLaunchKernelGGL(pw_render_patch_kernel<16>, dim3(static_cast<unsigned>((batch + 15) / 16)), dim3(256), 0, st, ra);
+    else
+      hipLaunchKernelGGL(pw_render_patch_kernel<32>, dim3(static_cast<unsigned>((batch + 7) / 8)), dim3(256), 0, st, ra);
+    return;
+  }
   const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
   if (e->fast_u8_ppc3)
     hipLaunchKernelGGL(pw_render_u8_ppc3_kernel, grid, block, e->render_lds, st, ra);
