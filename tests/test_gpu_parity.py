@@ -192,6 +192,46 @@ def test_full_small_images(golden, puzzles, torch_mod):
         assert (img == want).all(), (key, np.argwhere(img != want)[:5])
 
 
+@pytest.mark.parametrize("path", ["page", "copy"])
+def test_alternative_render_paths_match_lds_kernel(golden, torch_mod, path, monkeypatch):
+    """The opt-in page-ordered render paths (PUSHWORLD_AMD_RENDER=page|copy: static-image copy +
+    movable-cell patches) produce byte-identical observations to the default LDS kernel, on a
+    mixed Level-1 batch along random walks and on overlapping (illegal) states."""
+    torch = torch_mod
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    B, T = 2048, 25
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+
+    def make():
+        return VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, pixels_per_cell=3,
+                            border_width=1, observation="uint8", device=0, autoreset=True)
+
+    monkeypatch.setenv("PUSHWORLD_AMD_RENDER", "lds")
+    ref = make()
+    monkeypatch.setenv("PUSHWORLD_AMD_RENDER", path)
+    alt = make()
+    o_ref, o_alt = ref.reset(), alt.reset()
+    assert torch.equal(o_ref, o_alt)
+    gen = torch.Generator(device=ref.device)
+    gen.manual_seed(5)
+    acts = torch.randint(0, 4, (T, B), generator=gen, device=ref.device, dtype=torch.uint8)
+    for t in range(T):
+        o_ref = ref.step(acts[t])[0]
+        o_alt = alt.step(acts[t])[0]
+        assert torch.equal(ref.pos, alt.pos)
+        assert torch.equal(o_ref, o_alt), t
+    # overlapping states: every object at the position of its left neighbour in the state vector
+    pos = ref.states()
+    pos[:, 1:] = pos[:, :-1]
+    for v in (ref, alt):
+        v.set_states(pos)
+    assert torch.equal(ref.render(), alt.render())
+
+
 def test_fused_step_render_matches_reference(golden, puzzles, torch_mod):
     """pw_step_render (ONE launch: step in wave 0 + render) on a mixed batch: states, rewards,
     flags equal the golden trajectories and the observation equals the oracle's image of the
