@@ -1244,45 +1244,79 @@ __global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_generic_kernel(Re
   const int n_chunks = (a.obs_bytes + 15) >> 4;
   uint8_t* out = a.obs + static_cast<int64_t>(env) * a.env_stride;
 
+  // float32: the palette as exact uint8/255 values, staged next to the uint8 palette in LDS
+  float* palf = reinterpret_cast<float*>(l.flag + 4);
+  if (sizeof(T) == 4 && tid < 64) palf[tid] = a.pal_f32[tid >> 2][tid & 3];
+  __syncthreads();
+  constexpr int kPix = sizeof(T) == 1 ? 7 : 2;  // pixels a 16-byte chunk can touch
   for (int chunk = tid; chunk < n_chunks; chunk += PW_RENDER_THREADS) {
     const int elem0 = chunk * kElems;
-    int pix = elem0 / 3;
-    int ch = elem0 - pix * 3;
+    const int pix = elem0 / 3;
+    const int ch0 = elem0 - pix * 3;  // channel of the first element
+    // position of the first pixel: three divisions per chunk, then the walk below is incremental
     int Y = pix / wpx;
     int X = pix - Y * wpx;
-    uint32_t col = 0;
-    bool have = false;
+    int yp = Y - pady, xp = X - padx;
+    bool in_row = static_cast<unsigned>(yp) < static_cast<unsigned>(own_h);
+    int cy = in_row ? yp / ppc : 0;
+    int sy = yp - cy * ppc;
+    int zy = sy < bw ? 0 : (sy >= ppc - bw ? 2 : 1);
+    int cx = xp >= 0 ? xp / ppc : 0;
+    int sx = xp - cx * ppc;  // negative while left of the puzzle
+    uint32_t rgb[kPix];
+#pragma unroll
+    for (int j = 0; j < kPix; j++) {
+      uint32_t col = PW_C_PAD;
+      if (in_row && static_cast<unsigned>(xp) < static_cast<unsigned>(own_w)) {
+        const int zx = sx < bw ? 0 : (sx >= ppc - bw ? 2 : 1);
+        col = (E[(3 * cy + zy) * pv.W + cx] >> (4 * zx)) & 15u;
+      }
+      rgb[j] = sizeof(T) == 1 ? pal[col] : col;
+      // next pixel
+      xp++;
+      if (++sx == ppc) {  // sx < 0 while left of the puzzle: reaches 0 together with xp
+        sx = 0;
+        cx++;
+      }
+      if (xp == wpx - padx) {  // row wrap (X == wpx)
+        xp = -padx;
+        cx = 0;
+        sx = -padx;
+        yp++;
+        in_row = static_cast<unsigned>(yp) < static_cast<unsigned>(own_h);
+        if (in_row && ++sy == ppc) {
+          sy = 0;
+          cy++;
+        }
+        if (yp == 0) {
+          sy = 0;
+          cy = 0;
+        }
+        zy = sy < bw ? 0 : (sy >= ppc - bw ? 2 : 1);
+      }
+    }
     union {
       uint4 v;
-      uint8_t u8[16];
+      uint32_t u32[4];
       float f32[4];
     } o;
+    if (sizeof(T) == 1) {
+      // 7 pixels = 21 bytes, the chunk is bytes [ch0, ch0 + 16) of them
+      const uint32_t d0 = rgb[0] | (rgb[1] << 24);
+      const uint32_t d1 = (rgb[1] >> 8) | (rgb[2] << 16);
+      const uint32_t d2 = (rgb[2] >> 16) | (rgb[3] << 8);
+      const uint32_t d3 = rgb[4] | (rgb[5] << 24);
+      const uint32_t d4 = (rgb[5] >> 8) | (rgb[6 < kPix ? 6 : 0] << 16);
+      const uint32_t bs = static_cast<uint32_t>(ch0);
+      o.u32[0] = __builtin_amdgcn_alignbyte(d1, d0, bs);
+      o.u32[1] = __builtin_amdgcn_alignbyte(d2, d1, bs);
+      o.u32[2] = __builtin_amdgcn_alignbyte(d3, d2, bs);
+      o.u32[3] = __builtin_amdgcn_alignbyte(d4, d3, bs);
+    } else {
 #pragma unroll
-    for (int k = 0; k < kElems; k++) {
-      if (!have) {
-        const int yp = Y - pady, xp = X - padx;
-        col = PW_C_PAD;
-        if (static_cast<unsigned>(yp) < static_cast<unsigned>(own_h) &&
-            static_cast<unsigned>(xp) < static_cast<unsigned>(own_w)) {
-          const int cy = yp / ppc, sy = yp - cy * ppc;
-          const int cx = xp / ppc, sx = xp - cx * ppc;
-          const int zy = sy < bw ? 0 : (sy >= ppc - bw ? 2 : 1);
-          const int zx = sx < bw ? 0 : (sx >= ppc - bw ? 2 : 1);
-          col = (E[(3 * cy + zy) * pv.W + cx] >> (4 * zx)) & 15u;
-        }
-        have = true;
-      }
-      if (sizeof(T) == 1)
-        o.u8[k] = static_cast<uint8_t>(pal[col] >> (8 * ch));
-      else
-        o.f32[k] = a.pal_f32[col][ch];
-      if (++ch == 3) {
-        ch = 0;
-        have = false;
-        if (++X == wpx) {
-          X = 0;
-          Y++;
-        }
+      for (int k = 0; k < 4; k++) {
+        const int e = ch0 + k;  // element k belongs to pixel e / 3, channel e % 3
+        o.f32[k] = palf[rgb[e >= 3 ? 1 : 0] * 4 + (e >= 3 ? e - 3 : e)];
       }
     }
     *reinterpret_cast<uint4*>(out + static_cast<int64_t>(chunk) * 16) = o.v;
@@ -1411,7 +1445,7 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
               static_cast<uint16_t>(pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_zone_border_bits(gm, zy)));
       }
   }
-  e->render_lds = 16 + max_e_bytes + 64 + 64 + 16;
+  e->render_lds = 16 + max_e_bytes + 64 + 64 + 16 + 256;  // guard, E, spos, pal, flag, float palette
   for (int i = 0; i < 16; i++) {
     e->pal_rgb[i] = 0;
     for (int c = 0; c < 4; c++) e->pal_f32[i][c] = 0.0f;
