@@ -224,6 +224,22 @@ def main():
                 "launch_gap_ms": 1000.0 * elapsed / K - float(ms.mean()),
             }
             out["config"]["algorithmic_bytes_per_env_step"] = eng.obs_bytes + state_bytes
+        # extra (not the headline): the same batch state-only, T steps per launch (pw_rollout)
+        try:
+            Tn = 64
+            racts = torch.randint(0, 4, (Tn, B), generator=gen, device=dev, dtype=torch.uint8)
+            vec.rollout(racts)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                vec.rollout(racts)
+            e1.record()
+            torch.cuda.synchronize()
+            out["state_only_rollout"] = {"env_steps_per_s": 4 * Tn * B / (e0.elapsed_time(e1) * 1e-3),
+                                          "steps_per_launch": Tn, "envs": B, "n_gpus": 1}
+        except Exception as exc:  # noqa: BLE001
+            out["state_only_rollout"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(paths, ids, args.max_steps, eng.obs_shape[0] // args.ppc,

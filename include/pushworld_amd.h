@@ -148,6 +148,17 @@ int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_
             int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
             uint8_t* truncated, int32_t batch, uint32_t flags, void* stream);
 
+/* num_steps consecutive pw_step calls of every environment in ONE launch (state-only rollouts:
+ * planner look-ahead, random-policy data, configs C2/C4).  actions is uint8 [num_steps][B],
+ * step-major.  Semantics are exactly those of calling pw_step num_steps times with actions[t];
+ * pos/steps/reward/dgoals/terminated/truncated receive the values after the last step.  The
+ * optional histories reward_hist float64 [num_steps][B], terminated_hist / truncated_hist
+ * uint8 [num_steps][B] (NULL to skip) receive every step's outputs. */
+int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int32_t num_steps,
+               int8_t* pos, int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
+               uint8_t* truncated, double* reward_hist, uint8_t* terminated_hist,
+               uint8_t* truncated_hist, int32_t batch, uint32_t flags, void* stream);
+
 /* puzzle.py:426-469 render() + env_utils.py:44-91 padding (+ /255 for PW_OBS_F32).
  * obs: device buffer, env e at obs + e * env_stride_bytes (multiple of 16, base 16 B aligned). */
 int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs,

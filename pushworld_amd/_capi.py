@@ -82,6 +82,11 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
          c_uint32, c_void_p],
     ),
+    "pw_rollout": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_int32, c_uint32, c_void_p],
+    ),
     "pw_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_step_render": (
         c_int,
@@ -298,6 +303,13 @@ class Engine:
     def step(self, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, flags=0):
         check(lib.pw_step(self.handle, _ptr(puzzle_id), _ptr(actions), _ptr(pos), _ptr(steps), _ptr(reward),
                           _ptr(dgoals), _ptr(terminated), _ptr(truncated), pos.shape[0], flags, self._stream()))
+
+    def rollout(self, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, reward_hist=None,
+                terminated_hist=None, truncated_hist=None, flags=0):
+        """``actions``: uint8 [T, B] (step-major)."""
+        check(lib.pw_rollout(self.handle, _ptr(puzzle_id), _ptr(actions), actions.shape[0], _ptr(pos), _ptr(steps),
+                             _ptr(reward), _ptr(dgoals), _ptr(terminated), _ptr(truncated), _ptr(reward_hist),
+                             _ptr(terminated_hist), _ptr(truncated_hist), pos.shape[0], flags, self._stream()))
 
     def render(self, puzzle_id, pos, obs_storage):
         check(lib.pw_render(self.handle, _ptr(puzzle_id), _ptr(pos), _ptr(obs_storage), self.obs_stride,

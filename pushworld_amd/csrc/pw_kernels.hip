@@ -451,72 +451,78 @@ __device__ __forceinline__ int lane_pos(const uint32_t (&P)[NP / 2], int j) {
   return static_cast<int>((v >> (16 * (j & 1))) & 0xffffu);
 }
 
+// Per-lane environment state kept in registers between the steps of a rollout.
 template <int NP>
-__global__ __launch_bounds__(256) void pw_step_lane_kernel(StepArgs a) {
-  const int env = blockIdx.x * 256 + threadIdx.x;
-  if (env >= a.batch) return;
-  const int pid = a.puzzle_id[env];
-  const int act = a.actions[env];
-  const int was_done = a.term[env] | a.trunc[env];
-  const int steps_in = a.steps[env];
-  uint32_t* prow = reinterpret_cast<uint32_t*>(a.pos) + static_cast<int64_t>(env) * (NP / 2);
-  uint32_t P[NP / 2];
+struct LaneEnv {
+  uint32_t P[NP / 2];  // packed (x, y) int8 pairs, two objects per dword
+  int steps;
+  int term, trunc;     // flags of the last step (0 / 1 / 0xFF)
+  double reward;
+  int dgoals;
+};
+
+template <int NP>
+__device__ __forceinline__ void lane_load(const StepArgs& a, int env, LaneEnv<NP>& s) {
+  const uint32_t* prow = reinterpret_cast<const uint32_t*>(a.pos) + static_cast<int64_t>(env) * (NP / 2);
   if (NP == 4) {
     const uint2 v = *reinterpret_cast<const uint2*>(prow);
-    P[0] = v.x;
-    P[1] = v.y;
+    s.P[0] = v.x;
+    s.P[1] = v.y;
   } else {
 #pragma unroll
     for (int k = 0; k < NP / 8; k++) {
       const uint4 v = reinterpret_cast<const uint4*>(prow)[k];
-      P[4 * k + 0] = v.x;
-      P[4 * k + 1] = v.y;
-      P[4 * k + 2] = v.z;
-      P[4 * k + 3] = v.w;
+      s.P[4 * k + 0] = v.x;
+      s.P[4 * k + 1] = v.y;
+      s.P[4 * k + 2] = v.z;
+      s.P[4 * k + 3] = v.w;
     }
   }
-  const PwPuzzleHeader* h = a.hdrs + pid;
-  LanePuzzle p;
-  p.h = h;
-  const uint8_t* b = a.blob + h->base;
-  p.wall = reinterpret_cast<const uint64_t*>(b + h->off_wall);
-  p.awall = reinterpret_cast<const uint64_t*>(b + h->off_awall);
-  p.shapes = reinterpret_cast<const uint64_t*>(b + h->off_shapes);
-  p.H = h->H;
-  p.N = h->N;
-  p.G = h->G;
+  s.steps = a.steps[env];
+  s.term = a.term[env];
+  s.trunc = a.trunc[env];
+  s.reward = 0.0;
+  s.dgoals = 0;
+}
 
-  if ((a.flags & PW_STEP_AUTORESET) && was_done) {
+template <int NP>
+__device__ __forceinline__ void lane_store_pos(const StepArgs& a, int env, const LaneEnv<NP>& s) {
+  uint32_t* prow = reinterpret_cast<uint32_t*>(a.pos) + static_cast<int64_t>(env) * (NP / 2);
+  if (NP == 4) {
+    *reinterpret_cast<uint2*>(prow) = make_uint2(s.P[0], s.P[1]);
+  } else {
 #pragma unroll
-    for (int k = 0; k < NP / 2; k++) prow[k] = reinterpret_cast<const uint32_t*>(h->init)[k];
-    a.steps[env] = 0;
-    a.term[env] = 0;
-    a.trunc[env] = 0;
-    if (a.reward) a.reward[env] = 0.0;
-    if (a.dgoals) a.dgoals[env] = 0;
-    return;
+    for (int k = 0; k < NP / 8; k++)
+      reinterpret_cast<uint4*>(prow)[k] = make_uint4(s.P[4 * k], s.P[4 * k + 1], s.P[4 * k + 2], s.P[4 * k + 3]);
   }
-  if (act > 3) {
-    a.term[env] = 0xFF;
-    a.trunc[env] = 0xFF;
-    return;
+}
+
+// One pw_step of one environment on one lane (gym_env.py:188-226 minus the observation).
+// Returns true when the positions changed.
+template <int NP>
+__device__ __forceinline__ bool lane_step(const LanePuzzle& p, const PwPuzzleHeader* h, const uint32_t (&OT)[NP],
+                                          LaneEnv<NP>& s, int act, uint32_t flags, int max_steps) {
+  if ((flags & PW_STEP_AUTORESET) && (s.term | s.trunc)) {
+    // next-step autoreset: this step is the reset() of a finished episode
+#pragma unroll
+    for (int k = 0; k < NP / 2; k++) s.P[k] = reinterpret_cast<const uint32_t*>(h->init)[k];
+    s.steps = 0;
+    s.term = 0;
+    s.trunc = 0;
+    s.reward = 0.0;
+    s.dgoals = 0;
+    return true;
+  }
+  if (act > 3) {  // not in Discrete(4): flag and leave the env untouched (gym_env.py:195-196)
+    s.term = 0xFF;
+    s.trunc = 0xFF;
+    return false;
   }
   const int dx = act == 0 ? -1 : (act == 1 ? 1 : 0);
   const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
 
-  // the whole object table (bounding boxes + shape-row offsets) with wide loads
-  uint32_t OT[NP];
-#pragma unroll
-  for (int k = 0; k < NP / 4; k++) {
-    const uint4 v = reinterpret_cast<const uint4*>(h->objtab)[k];
-    OT[4 * k + 0] = v.x;
-    OT[4 * k + 1] = v.y;
-    OT[4 * k + 2] = v.z;
-    OT[4 * k + 3] = v.w;
-  }
-
   uint32_t pushed = 0;
-  const LaneObj agent = lane_obj(OT[0], static_cast<int>(P[0] & 0xffffu));
+  const LaneObj agent = lane_obj(OT[0], static_cast<int>(s.P[0] & 0xffffu));
   if (!lane_agent_blocked(p, agent, act)) {  // puzzle.py:353
     pushed = 1u;
     uint32_t frontier = 0;
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(256) void pw_step_lane_kernel(StepArgs a) {
 #pragma unroll
     for (int j = 1; j < NP; j++) {
       if (j < p.N && !blocked) {
-        const LaneObj oj = lane_obj(OT[j], static_cast<int>((P[j >> 1] >> (16 * (j & 1))) & 0xffffu));
+        const LaneObj oj = lane_obj(OT[j], static_cast<int>((s.P[j >> 1] >> (16 * (j & 1))) & 0xffffu));
         if (lane_pushes(p, agent, oj, act, dx, dy)) {
           if (lane_blocked(p, oj, p.wall, act)) {
             blocked = true;  // transitive stopping
@@ -540,10 +546,10 @@ __global__ __launch_bounds__(256) void pw_step_lane_kernel(StepArgs a) {
     while (frontier && !blocked) {
       const int i = __ffs(frontier) - 1;
       frontier &= frontier - 1;
-      const LaneObj oi = lane_obj(reinterpret_cast<const uint32_t*>(h->objtab)[i], lane_pos<NP>(P, i));
+      const LaneObj oi = lane_obj(reinterpret_cast<const uint32_t*>(h->objtab)[i], lane_pos<NP>(s.P, i));
       for (int j = 1; j < p.N && !blocked; j++) {
         if ((pushed >> j) & 1u) continue;
-        const LaneObj oj = lane_obj(reinterpret_cast<const uint32_t*>(h->objtab)[j], lane_pos<NP>(P, j));
+        const LaneObj oj = lane_obj(reinterpret_cast<const uint32_t*>(h->objtab)[j], lane_pos<NP>(s.P, j));
         if (lane_pushes(p, oi, oj, act, dx, dy)) {
           if (lane_blocked(p, oj, p.wall, act)) {
             blocked = true;
@@ -562,12 +568,12 @@ __global__ __launch_bounds__(256) void pw_step_lane_kernel(StepArgs a) {
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     const uint32_t sh = 16 * (j & 1);
-    const uint32_t cur = (P[j >> 1] >> sh) & 0xffffu;
+    const uint32_t cur = (s.P[j >> 1] >> sh) & 0xffffu;
     uint32_t nxt = cur;
     if ((pushed >> j) & 1u) {
       const int x = static_cast<int8_t>(cur & 0xff) + dx, y = static_cast<int8_t>((cur >> 8) & 0xff) + dy;
       nxt = static_cast<uint32_t>(x & 0xff) | (static_cast<uint32_t>(y & 0xff) << 8);
-      P[j >> 1] = (P[j >> 1] & ~(0xffffu << sh)) | (nxt << sh);
+      s.P[j >> 1] = (s.P[j >> 1] & ~(0xffffu << sh)) | (nxt << sh);
     }
     if (j >= 1 && j <= p.G) {
       const uint32_t g = reinterpret_cast<const uint16_t*>(h->goal)[j - 1];
@@ -575,22 +581,98 @@ __global__ __launch_bounds__(256) void pw_step_lane_kernel(StepArgs a) {
       after += nxt == g;
     }
   }
-  if (pushed) {
-    if (NP == 4) {
-      *reinterpret_cast<uint2*>(prow) = make_uint2(P[0], P[1]);
-    } else {
+  const bool terminated = after == p.G;  // vacuously true without goals (trap T8)
+  s.steps += 1;
+  s.term = terminated ? 1 : 0;
+  s.trunc = (max_steps > 0 && s.steps >= max_steps) ? 1 : 0;
+  // gym_env.py:212-221: python float arithmetic == IEEE double here
+  s.reward = terminated ? 10.0 : static_cast<double>(after - before) - 0.01;
+  s.dgoals = after - before;
+  return pushed != 0;
+}
+
+template <int NP>
+__device__ __forceinline__ void lane_puzzle(const StepArgs& a, int pid, LanePuzzle& p, uint32_t (&OT)[NP]) {
+  const PwPuzzleHeader* h = a.hdrs + pid;
+  p.h = h;
+  const uint8_t* b = a.blob + h->base;
+  p.wall = reinterpret_cast<const uint64_t*>(b + h->off_wall);
+  p.awall = reinterpret_cast<const uint64_t*>(b + h->off_awall);
+  p.shapes = reinterpret_cast<const uint64_t*>(b + h->off_shapes);
+  p.H = h->H;
+  p.N = h->N;
+  p.G = h->G;
+  // the whole object table (bounding boxes + shape-row offsets) with wide loads
 #pragma unroll
-      for (int k = 0; k < NP / 8; k++)
-        reinterpret_cast<uint4*>(prow)[k] = make_uint4(P[4 * k], P[4 * k + 1], P[4 * k + 2], P[4 * k + 3]);
-    }
+  for (int k = 0; k < NP / 4; k++) {
+    const uint4 v = reinterpret_cast<const uint4*>(h->objtab)[k];
+    OT[4 * k + 0] = v.x;
+    OT[4 * k + 1] = v.y;
+    OT[4 * k + 2] = v.z;
+    OT[4 * k + 3] = v.w;
   }
-  const bool terminated = after == p.G;
-  const int s = steps_in + 1;
-  a.steps[env] = s;
-  a.term[env] = terminated ? 1 : 0;
-  a.trunc[env] = (a.max_steps > 0 && s >= a.max_steps) ? 1 : 0;
-  if (a.reward) a.reward[env] = terminated ? 10.0 : static_cast<double>(after - before) - 0.01;
-  if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(after - before);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void pw_step_lane_kernel(StepArgs a) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= a.batch) return;
+  const int act = a.actions[env];
+  LaneEnv<NP> s;
+  lane_load<NP>(a, env, s);
+  LanePuzzle p;
+  uint32_t OT[NP];
+  lane_puzzle<NP>(a, a.puzzle_id[env], p, OT);
+  const int t0 = s.term, u0 = s.trunc;
+  const bool changed = lane_step<NP>(p, p.h, OT, s, act, a.flags, a.max_steps);
+  if (changed) lane_store_pos<NP>(a, env, s);
+  if (act > 3 && !((a.flags & PW_STEP_AUTORESET) && (t0 | u0))) {
+    a.term[env] = 0xFF;
+    a.trunc[env] = 0xFF;
+    return;
+  }
+  a.steps[env] = s.steps;
+  a.term[env] = static_cast<uint8_t>(s.term);
+  a.trunc[env] = static_cast<uint8_t>(s.trunc);
+  if (a.reward) a.reward[env] = s.reward;
+  if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(s.dgoals);
+}
+
+// K1c rollout: T consecutive steps of every environment in ONE launch.  The environment lives in
+// registers between steps; puzzle tables are L1 hits after the first step.
+struct RolloutArgs {
+  StepArgs s;              // actions = uint8 [T][B]
+  int32_t num_steps;
+  double* reward_hist;     // optional [T][B]
+  uint8_t* term_hist;      // optional [T][B]
+  uint8_t* trunc_hist;     // optional [T][B]
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void pw_rollout_lane_kernel(RolloutArgs r) {
+  const StepArgs& a = r.s;
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= a.batch) return;
+  LaneEnv<NP> s;
+  lane_load<NP>(a, env, s);
+  LanePuzzle p;
+  uint32_t OT[NP];
+  lane_puzzle<NP>(a, a.puzzle_id[env], p, OT);
+  bool changed = false;
+  for (int t = 0; t < r.num_steps; t++) {
+    const int64_t o = static_cast<int64_t>(t) * a.batch + env;
+    const int act = a.actions[o];
+    changed = lane_step<NP>(p, p.h, OT, s, act, a.flags, a.max_steps) || changed;
+    if (r.reward_hist) r.reward_hist[o] = s.reward;
+    if (r.term_hist) r.term_hist[o] = static_cast<uint8_t>(s.term);
+    if (r.trunc_hist) r.trunc_hist[o] = static_cast<uint8_t>(s.trunc);
+  }
+  if (changed) lane_store_pos<NP>(a, env, s);
+  a.steps[env] = s.steps;
+  a.term[env] = static_cast<uint8_t>(s.term);
+  a.trunc[env] = static_cast<uint8_t>(s.trunc);
+  if (a.reward) a.reward[env] = s.reward;
+  if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(s.dgoals);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1617,6 +1699,30 @@ int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_
     default: hipLaunchKernelGGL(pw_step_lane_kernel<32>, grid, block, 0, st, a); break;
   }
   return check_launch("pw_step");
+}
+
+int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int32_t num_steps, int8_t* pos,
+               int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated,
+               double* reward_hist, uint8_t* terminated_hist, uint8_t* truncated_hist, int32_t batch, uint32_t flags,
+               void* stream) {
+  RolloutArgs r;
+  int rc = fill_step_args(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, batch, flags, &r.s);
+  if (rc != PW_OK) return rc;
+  if (num_steps < 0) return pw_fail(PW_EINVAL, "num_steps must be >= 0");
+  if (batch <= 0 || num_steps == 0) return PW_OK;
+  r.num_steps = num_steps;
+  r.reward_hist = reward_hist;
+  r.term_hist = terminated_hist;
+  r.trunc_hist = truncated_hist;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
+  switch (e->np) {
+    case 4: hipLaunchKernelGGL(pw_rollout_lane_kernel<4>, grid, block, 0, st, r); break;
+    case 8: hipLaunchKernelGGL(pw_rollout_lane_kernel<8>, grid, block, 0, st, r); break;
+    case 16: hipLaunchKernelGGL(pw_rollout_lane_kernel<16>, grid, block, 0, st, r); break;
+    default: hipLaunchKernelGGL(pw_rollout_lane_kernel<32>, grid, block, 0, st, r); break;
+  }
+  return check_launch("pw_rollout");
 }
 
 int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs, int64_t env_stride_bytes,

@@ -116,6 +116,30 @@ class VecPushWorld:
                 self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
         return self.obs, self.reward, self.terminated, self.truncated
 
+    def rollout(self, actions: torch.Tensor, history: bool = False):
+        """T steps in ONE launch without observations (``pw_rollout``): ``actions`` is a uint8 tensor
+        [T, B] on the device.  Same semantics as T calls of ``step`` with ``observation=None``.
+
+        Returns ``(reward, terminated, truncated)`` of the last step, or, with ``history=True``,
+        the per-step tensors of shape [T, B].
+        """
+        if not self._has_reset:
+            raise RuntimeError("reset() must be called before step() can be called.")
+        if actions.dtype != torch.uint8 or actions.device != self.device or actions.dim() != 2 \
+                or actions.shape[1] != self.num_envs or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous uint8 tensor of shape [T, num_envs] on the engine's device")
+        T = actions.shape[0]
+        rh = th = uh = None
+        if history:
+            rh = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
+            th = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+            uh = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+        self.engine.rollout(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals, self.terminated,
+                            self.truncated, rh, th, uh, self.flags)
+        if history:
+            return rh, th, uh
+        return self.reward, self.terminated, self.truncated
+
     def render(self):
         """Re-renders the current states into the observation buffer and returns it."""
         if self.obs is None:

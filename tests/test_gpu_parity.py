@@ -277,3 +277,48 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod):
                 o = oracles[k]
                 st = tuple(map(tuple, want.tolist()))
                 assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
+
+
+@pytest.mark.parametrize("autoreset", [False, True])
+def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset):
+    """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's
+    reward / terminated / truncated, on a mixed batch, with and without next-step autoreset; the
+    per-step history of the plan sequences also equals the golden rewards of the reference."""
+    torch = torch_mod
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith(("bench:", "pytest:"))]
+    pool = [puzzles[k] for k in keys]
+    envs = []
+    for pi, k in enumerate(keys):
+        for seq in golden.sequences(k):
+            if seq[0] in ("plan", "rand"):
+                envs.append((pi, k, seq))
+    B, T = len(envs), 150
+    actions = np.zeros((T, B), np.uint8)
+    for b, (_, _, seq) in enumerate(envs):
+        n = min(T, len(seq[1]))
+        actions[:n, b] = seq[1][:n]
+        actions[n:, b] = (np.arange(T - n) + b) % 4
+    acts = torch.as_tensor(actions).to("cuda:0")
+    ids = [e[0] for e in envs]
+    a = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset)
+    b_ = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset)
+    a.reset()
+    b_.reset()
+    rh, th, uh = a.rollout(acts, history=True)
+    rr = np.zeros((T, B), np.float64)
+    tt = np.zeros((T, B), np.uint8)
+    uu = np.zeros((T, B), np.uint8)
+    for t in range(T):
+        _, r, te, tr = b_.step(acts[t])
+        rr[t], tt[t], uu[t] = r.cpu().numpy(), te.cpu().numpy(), tr.cpu().numpy()
+    assert (rh.cpu().numpy().view(np.uint64) == rr.view(np.uint64)).all()
+    assert (th.cpu().numpy() == tt).all() and (uh.cpu().numpy() == uu).all()
+    assert torch.equal(a.pos, b_.pos) and torch.equal(a.steps, b_.steps)
+    assert torch.equal(a.reward, b_.reward) and torch.equal(a.terminated, b_.terminated)
+    if not autoreset:
+        for b, (_, k, seq) in enumerate(envs):
+            n = min(T, len(seq[1]))
+            assert (rr[:n, b].view(np.uint64) == seq[4][:n].view(np.uint64)).all(), k
+            assert (tt[:n, b] == seq[5][:n]).all(), k
