@@ -42,7 +42,7 @@ struct PwEngine {
   int64_t obs_bytes;
   size_t render_lds;
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
-  bool step_wave_kernel;   // pw_step uses the wavefront-per-env kernel instead of lane-per-env
+  int step_kernel;         // 0 group (default), 1 wavefront per env, 2 lane per env (PUSHWORLD_AMD_STEP)
   bool two_pass_render;    // PUSHWORLD_AMD_RENDER=copy: copy kernel + patch kernel instead of the page kernel
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (copy+patch render path)
   int64_t simg_stride;     // bytes between the static images of consecutive puzzles
@@ -673,6 +673,140 @@ __global__ __launch_bounds__(256) void pw_rollout_lane_kernel(RolloutArgs r) {
   a.trunc[env] = static_cast<uint8_t>(s.trunc);
   if (a.reward) a.reward[env] = s.reward;
   if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(s.dgoals);
+}
+
+// ------------------------------------------------------------------------------------
+// K1d step / rollout, GS lanes per environment (lane j of a group = movable j)
+//
+// The lane-per-env kernel above is bound by the latency of its serial loop over the objects with
+// one wave per SIMD; here the objects of an environment are tested in parallel (each lane asks
+// "does the current pusher push MY object, and am I wall-blocked?"), the push set grows by ballots
+// inside the 16- or 32-lane group, and a 65 536-env batch is 16 k waves instead of 1 k, so the
+// remaining L1/L2 latencies overlap.  Default kernel of pw_step and pw_rollout.
+// ------------------------------------------------------------------------------------
+template <int GS>
+__global__ __launch_bounds__(256) void pw_step_group_kernel(RolloutArgs r) {
+  const StepArgs& a = r.s;
+  constexpr int kGroups = 256 / GS;
+  const int lane = threadIdx.x & (PW_WAVE - 1);
+  const int lj = threadIdx.x & (GS - 1);
+  const int gbase = lane & ~(GS - 1);
+  const unsigned long long gmask = ((1ull << (GS - 1) << 1) - 1ull) << gbase;
+  const int env = blockIdx.x * kGroups + static_cast<int>(threadIdx.x) / GS;
+  const bool live = env < a.batch;
+  const int e = live ? env : 0;
+
+  const int pid = a.puzzle_id[e];
+  LanePuzzle p;
+  const PwPuzzleHeader* h = a.hdrs + pid;
+  p.h = h;
+  {
+    const uint8_t* b = a.blob + h->base;
+    p.wall = reinterpret_cast<const uint64_t*>(b + h->off_wall);
+    p.awall = reinterpret_cast<const uint64_t*>(b + h->off_awall);
+    p.shapes = reinterpret_cast<const uint64_t*>(b + h->off_shapes);
+  }
+  p.H = h->H;
+  p.N = live ? h->N : 0;
+  p.G = h->G;
+  const int N = p.N;
+  int16_t* prow = reinterpret_cast<int16_t*>(a.pos) + static_cast<int64_t>(e) * a.np;
+  int xy = (lj < N) ? static_cast<int>(static_cast<uint16_t>(prow[lj])) : 0;
+  const uint32_t ot = (lj < N) ? reinterpret_cast<const uint32_t*>(h->objtab)[lj] : 0u;
+  const bool is_goal_lane = live && lj >= 1 && lj <= p.G;
+  const int gxy = is_goal_lane ? static_cast<int>(reinterpret_cast<const uint16_t*>(h->goal)[lj - 1]) : -1;
+  int steps = a.steps[e], term = a.term[e], trunc = a.trunc[e];
+  double reward = 0.0;
+  int dgoals = 0;
+  bool changed = false, any_played = false;
+
+  for (int t = 0; t < r.num_steps; t++) {
+    const int64_t o = static_cast<int64_t>(t) * a.batch + e;
+    const int act = live ? static_cast<int>(a.actions[o]) : 0;
+    const bool do_reset = live && (a.flags & PW_STEP_AUTORESET) && (term | trunc);
+    const bool bad = live && !do_reset && act > 3;
+    const bool play = live && !do_reset && !bad;
+    const int dx = act == 0 ? -1 : (act == 1 ? 1 : 0);
+    const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
+    const LaneObj me = lane_obj(ot, xy);
+
+    // agent against walls + agent walls (puzzle.py:353), evaluated by the group's lane 0
+    bool agent_blk = false;
+    if (play && lj == 0) agent_blk = lane_agent_blocked(p, me, act);
+    bool dead = (__ballot(agent_blk) & gmask) != 0ull;
+    uint32_t pushed = 1u, frontier = 0u;
+    int cur = 0;
+    bool active = play && !dead;
+    // push-set fixed point: every lane tests the group's current pusher against its own object
+    while (__ballot(active) != 0ull) {
+      const int pxy = __shfl(xy, gbase + cur, PW_WAVE);
+      const uint32_t pot = static_cast<uint32_t>(__shfl(static_cast<int>(ot), gbase + cur, PW_WAVE));
+      bool hit = false, blk = false;
+      if (active && lj >= 1 && lj < N && !((pushed >> lj) & 1u)) {
+        hit = lane_pushes(p, lane_obj(pot, pxy), me, act, dx, dy);
+        if (hit) blk = lane_blocked(p, me, p.wall, act);  // transitive stopping (puzzle.py:376-379)
+      }
+      const unsigned long long hm = __ballot(hit), bk = __ballot(blk);
+      const uint32_t fresh = static_cast<uint32_t>((hm & gmask) >> gbase);
+      if ((bk & gmask) != 0ull) dead = true;
+      pushed |= fresh;
+      frontier |= fresh;
+      active = active && !dead && frontier != 0u;
+      if (active) {
+        cur = __ffs(frontier) - 1;
+        frontier &= frontier - 1u;
+      }
+    }
+    const uint32_t moved = (play && !dead) ? pushed : 0u;
+
+    // displaced state + goal bookkeeping (puzzle.py:384-411)
+    int nxy = xy;
+    if ((moved >> lj) & 1u) {
+      const int x = static_cast<int8_t>(xy & 0xff) + dx, y = static_cast<int8_t>((xy >> 8) & 0xff) + dy;
+      nxy = (x & 0xff) | ((y & 0xff) << 8);
+    }
+    const int before = __popcll(__ballot(is_goal_lane && xy == gxy) & gmask);
+    const int after = __popcll(__ballot(is_goal_lane && nxy == gxy) & gmask);
+    if (play) {
+      xy = nxy;
+      changed = changed || moved != 0u;
+      const bool terminated = after == p.G;  // vacuously true without goals (trap T8)
+      steps += 1;
+      term = terminated ? 1 : 0;
+      trunc = (a.max_steps > 0 && steps >= a.max_steps) ? 1 : 0;
+      reward = terminated ? 10.0 : static_cast<double>(after - before) - 0.01;  // gym_env.py:212-221
+      dgoals = after - before;
+      any_played = true;
+    } else if (do_reset) {
+      xy = (lj < N) ? static_cast<int>(reinterpret_cast<const uint16_t*>(h->init)[lj]) : 0;
+      changed = true;
+      steps = 0;
+      term = 0;
+      trunc = 0;
+      reward = 0.0;
+      dgoals = 0;
+      any_played = true;
+    } else if (bad) {  // not in Discrete(4): flag, leave the env untouched (gym_env.py:195-196)
+      term = 0xFF;
+      trunc = 0xFF;
+    }
+    if (live && lj == 0) {
+      if (r.reward_hist) r.reward_hist[o] = reward;
+      if (r.term_hist) r.term_hist[o] = static_cast<uint8_t>(term);
+      if (r.trunc_hist) r.trunc_hist[o] = static_cast<uint8_t>(trunc);
+    }
+  }
+  if (!live) return;
+  if (changed && lj < a.np) prow[lj] = static_cast<int16_t>(xy);
+  if (lj == 0) {
+    a.term[env] = static_cast<uint8_t>(term);
+    a.trunc[env] = static_cast<uint8_t>(trunc);
+    if (any_played) {
+      a.steps[env] = steps;
+      if (a.reward) a.reward[env] = reward;
+      if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(dgoals);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1497,7 +1631,7 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   e->d_estat_off = nullptr;
   {
     const char* sel = getenv("PUSHWORLD_AMD_STEP");
-    e->step_wave_kernel = sel && std::string(sel) == "wave";
+    e->step_kernel = (sel && std::string(sel) == "wave") ? 1 : ((sel && std::string(sel) == "lane") ? 2 : 0);
   }
   // Static zone-colour tables (walls, agent walls, background, goal outlines) of every puzzle in
   // the layout the render kernel of this engine streams from: row stride pad_w with the puzzle
@@ -1679,6 +1813,13 @@ static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipS
     hipLaunchKernelGGL(pw_render_generic_kernel<float>, grid, block, e->render_lds, st, ra);
 }
 
+static void launch_group(PwEngine* e, const RolloutArgs& r, int32_t batch, hipStream_t st) {
+  if (e->np <= 16)
+    hipLaunchKernelGGL(pw_step_group_kernel<16>, dim3(static_cast<unsigned>((batch + 15) / 16)), dim3(256), 0, st, r);
+  else
+    hipLaunchKernelGGL(pw_step_group_kernel<32>, dim3(static_cast<unsigned>((batch + 7) / 8)), dim3(256), 0, st, r);
+}
+
 int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,
             double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, int32_t batch,
             uint32_t flags, void* stream) {
@@ -1687,17 +1828,27 @@ int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_
   if (rc != PW_OK) return rc;
   if (batch <= 0) return PW_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (e->step_wave_kernel) {  // PUSHWORLD_AMD_STEP=wave: one wavefront per environment
+  if (e->step_kernel == 1) {  // PUSHWORLD_AMD_STEP=wave: one wavefront per environment
     hipLaunchKernelGGL(pw_step_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0, st, a);
     return check_launch("pw_step");
   }
-  const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
-  switch (e->np) {
-    case 4: hipLaunchKernelGGL(pw_step_lane_kernel<4>, grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(pw_step_lane_kernel<8>, grid, block, 0, st, a); break;
-    case 16: hipLaunchKernelGGL(pw_step_lane_kernel<16>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(pw_step_lane_kernel<32>, grid, block, 0, st, a); break;
+  if (e->step_kernel == 2) {  // PUSHWORLD_AMD_STEP=lane: one lane per environment
+    const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
+    switch (e->np) {
+      case 4: hipLaunchKernelGGL(pw_step_lane_kernel<4>, grid, block, 0, st, a); break;
+      case 8: hipLaunchKernelGGL(pw_step_lane_kernel<8>, grid, block, 0, st, a); break;
+      case 16: hipLaunchKernelGGL(pw_step_lane_kernel<16>, grid, block, 0, st, a); break;
+      default: hipLaunchKernelGGL(pw_step_lane_kernel<32>, grid, block, 0, st, a); break;
+    }
+    return check_launch("pw_step");
   }
+  RolloutArgs r;
+  r.s = a;
+  r.num_steps = 1;
+  r.reward_hist = nullptr;
+  r.term_hist = nullptr;
+  r.trunc_hist = nullptr;
+  launch_group(e, r, batch, st);
   return check_launch("pw_step");
 }
 
@@ -1715,12 +1866,16 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
   r.term_hist = terminated_hist;
   r.trunc_hist = truncated_hist;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
-  switch (e->np) {
-    case 4: hipLaunchKernelGGL(pw_rollout_lane_kernel<4>, grid, block, 0, st, r); break;
-    case 8: hipLaunchKernelGGL(pw_rollout_lane_kernel<8>, grid, block, 0, st, r); break;
-    case 16: hipLaunchKernelGGL(pw_rollout_lane_kernel<16>, grid, block, 0, st, r); break;
-    default: hipLaunchKernelGGL(pw_rollout_lane_kernel<32>, grid, block, 0, st, r); break;
+  if (e->step_kernel == 2) {
+    const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
+    switch (e->np) {
+      case 4: hipLaunchKernelGGL(pw_rollout_lane_kernel<4>, grid, block, 0, st, r); break;
+      case 8: hipLaunchKernelGGL(pw_rollout_lane_kernel<8>, grid, block, 0, st, r); break;
+      case 16: hipLaunchKernelGGL(pw_rollout_lane_kernel<16>, grid, block, 0, st, r); break;
+      default: hipLaunchKernelGGL(pw_rollout_lane_kernel<32>, grid, block, 0, st, r); break;
+    }
+  } else {
+    launch_group(e, r, batch, st);
   }
   return check_launch("pw_rollout");
 }

@@ -40,12 +40,13 @@ def _groups(golden):
     return g
 
 
-@pytest.mark.parametrize("group,kernel", [("bench", "lane"), ("tests", "lane"), ("l0", "lane"),
-                                          ("bench", "wave"), ("tests", "wave")])
+@pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
+                                          ("bench", "lane"), ("tests", "lane"), ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
     one mixed batch: positions, float64 reward bits, terminated, truncated, step counter.
-    pw_step has two kernels (one lane per env / one wavefront per env); both are checked."""
+    pw_step has three kernels (16/32 lanes per env = default, one lane per env, one wavefront per
+    env); all are checked."""
     torch = torch_mod
     monkeypatch.setenv("PUSHWORLD_AMD_STEP", kernel)
     from pushworld_amd.vec_env import VecPushWorld
@@ -98,7 +99,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["lane", "wave"])
+@pytest.mark.parametrize("kernel", ["group", "lane", "wave"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
@@ -279,12 +280,14 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod):
                 assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
 
 
+@pytest.mark.parametrize("kernel", ["group", "lane"])
 @pytest.mark.parametrize("autoreset", [False, True])
-def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset):
+def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):
     """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's
     reward / terminated / truncated, on a mixed batch, with and without next-step autoreset; the
     per-step history of the plan sequences also equals the golden rewards of the reference."""
     torch = torch_mod
+    monkeypatch.setenv("PUSHWORLD_AMD_STEP", kernel)
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = [k for k in golden.keys if k.startswith(("bench:", "pytest:"))]
