@@ -193,7 +193,7 @@ def test_full_small_images(golden, puzzles, torch_mod):
         assert (img == want).all(), (key, np.argwhere(img != want)[:5])
 
 
-@pytest.mark.parametrize("path", ["page", "copy"])
+@pytest.mark.parametrize("path", ["overlay", "page", "copy"])
 def test_alternative_render_paths_match_lds_kernel(golden, torch_mod, path, monkeypatch):
     """The opt-in page-ordered render paths (PUSHWORLD_AMD_RENDER=page|copy: static-image copy +
     movable-cell patches) produce byte-identical observations to the default LDS kernel, on a
