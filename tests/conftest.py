@@ -16,6 +16,10 @@ DATA = os.path.join(ROOT, "pushworld_amd", "data")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the HIP library is a build product (git-ignored): cross-compile it for gfx950 when missing or stale
+    from pushworld_amd import build as pw_build
+
+    pw_build.build(force=False)
 
 
 class GoldenData:
