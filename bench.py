@@ -212,13 +212,14 @@ def main():
                 try:
                     with open(pmc) as f:
                         rec = json.load(f)
-                    if rec.get("envs") == B and rec.get("obs_bytes") == eng.obs_bytes:
+                    if rec.get("envs") == B and rec.get("obs_bytes") == eng.obs_bytes and \
+                            rec.get("kernel") == eng.render_kernel and not args.fused:
                         traffic = rec.get("hbm_bytes_per_launch")
                 except Exception:  # noqa: BLE001
                     traffic = None
             out["roofline"] = {
-                "kernel": ("pw_render_u8_ppc3_kernel" if (args.obs == "uint8" and args.ppc == 3 and args.bw == 1)
-                           else "pw_render_generic_kernel") + (" (fused step + render)" if args.fused else ""),
+                "kernel": ("pw_render_u8_ppc3_kernel (fused step + render)" if (args.fused and eng.render_kernel != "pw_render_generic_kernel")
+                           else eng.render_kernel + (" (fused step + render)" if args.fused else "")),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -128,6 +128,8 @@ void pw_engine_destroy(PwEngine* e);
 int pw_engine_npad(const PwEngine* e);                 /* NP of the pos layout           */
 int pw_engine_obs_shape(const PwEngine* e, int* h, int* w, int* c); /* pixels             */
 int64_t pw_engine_obs_bytes(const PwEngine* e);        /* h*w*c*sizeof(elem), unpadded    */
+/* name of the kernel pw_render launches for this engine (profiling aid); returns its length */
+int pw_engine_render_kernel(const PwEngine* e, char* buf, int cap);
 int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride (16 B aligned) */
 
 /* gym_env.py:150-186 reset(): pos <- initial state of puzzle_id[e], steps <- 0,

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pw_engine_npad": (c_int, [c_void_p]),
     "pw_engine_obs_shape": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "pw_engine_obs_bytes": (c_int64, [c_void_p]),
+    "pw_engine_render_kernel": (c_int, [c_void_p, c_char_p, c_int]),
     "pw_engine_obs_stride": (c_int64, [c_void_p]),
     "pw_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "pw_step": (
@@ -270,6 +271,9 @@ class Engine:
         self.obs_bytes = lib.pw_engine_obs_bytes(h)
         self.obs_stride = lib.pw_engine_obs_stride(h)
         self.obs_dtype = torch.uint8 if obs_dtype == OBS_U8 else torch.float32
+        nb = ctypes.create_string_buffer(64)
+        check(lib.pw_engine_render_kernel(h, nb, 64))
+        self.render_kernel = nb.value.decode()
 
     def _stream(self):
         return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -1232,212 +1233,219 @@ __global__ __launch_bounds__(256) void pw_render_patch_kernel(RenderArgs a) {
 // list and recomputes only the chunks they touch from zone entries -- every byte of the
 // observation is written exactly once, as part of a full 16-byte store.
 // ------------------------------------------------------------------------------------
-#define PW_PAGE_ITEMS 1024
+#define PW_PAGE_ENTRIES 472  // zone entries a 4 KiB page can touch (4096 / 9 + margins), multiple of 8
 
-// entry q of environment `es` of the page: static entry unless an item of the list overrides it
-// (highest object index wins = painter order, puzzle.py:457)
-__device__ __forceinline__ uint32_t page_entry(const uint32_t* items, int n_items, const uint16_t* estat, int n_entries,
-                                               int q, int es) {
-  uint32_t e = (static_cast<unsigned>(q) < static_cast<unsigned>(n_entries)) ? estat[q] : 0u;
-  int best = -1;
-  const uint32_t key = (static_cast<uint32_t>(q) << 17) | (static_cast<uint32_t>(es) << 30);
-  for (int i = 0; i < n_items; i++) {
-    const uint32_t it = items[i];
-    if ((it & 0x7FFE0000u) == key) {
-      const int obj = (it >> 12) & 31;
-      if (obj > best) {
-        best = obj;
-        e = it & 0xFFFu;
-      }
+// geometry of one environment's image inside the frame (workgroup-uniform)
+struct PageEnv {
+  const PwPuzzleHeader* h;
+  const uint16_t* estat;
+  int W, H, N, G, n_mcells, c0, shift_bytes, n_entries;
+  int lo;     // byte offset of the page start inside this environment's image (may be negative)
+  int q_lo;   // first entry kept in the page's LDS entry window
+  uint32_t env;
+};
+
+__device__ __forceinline__ PageEnv page_env(const RenderArgs& a, int pid, uint32_t env, int lo) {
+  PageEnv pe;
+  pe.h = a.hdrs + pid;
+  pe.estat = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[pid]);
+  pe.W = pe.h->W;
+  pe.H = pe.h->H;
+  pe.N = pe.h->N;
+  pe.G = pe.h->G;
+  pe.n_mcells = static_cast<int>(pe.h->n_mcells);
+  const int pady = (a.pad_h - pe.H) * 3 / 2;
+  const int padx = (a.pad_w - pe.W) * 3 / 2;
+  pe.c0 = (padx + 2) / 3;
+  pe.shift_bytes = 3 * (pady * a.pad_w * 3 + padx - 3 * pe.c0);
+  pe.n_entries = 3 * pe.H * a.pad_w;
+  pe.lo = lo;
+  // entry holding byte lo is floor((lo - shift) / 9); two entries of margin (floor division)
+  const int t = lo - pe.shift_bytes;
+  pe.q_lo = (t >= 0 ? t / 9 : -((-t + 8) / 9)) - 2;
+  pe.env = env;
+  return pe;
+}
+
+// Movable cells of the environment that reach into the page [lo, lo + 4096): their zone entries go
+// into the page's LDS entry window `win` (atomicMax on (object + 1) << 12 | entry: the highest
+// object index wins = painter order, puzzle.py:457) and the chunks they touch are marked in
+// `dirty`.  page_prefilter() tells beforehand whether any object's rows meet the page at all.
+// lane j < N: packed position of movable j; `any` = some movable's rows meet the page
+__device__ __forceinline__ int page_prefilter(const RenderArgs& a, const PageEnv& pe, int lane, bool& any) {
+  const int row_bytes = 9 * a.pad_w;  // one image row
+  const int lo = pe.lo, hi = pe.lo + 4096;
+  int xy = 0;
+  bool hit = false;
+  if (lane < pe.N) {
+    xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(pe.env) * a.np + lane]);
+    const int y = static_cast<int8_t>((xy >> 8) & 0xff);
+    const int hh = pe.h->objtab[lane].h;
+    hit = 3 * y * row_bytes + pe.shift_bytes < hi && 3 * (y + hh) * row_bytes + pe.shift_bytes + 9 > lo;
+  }
+  any = __ballot(hit) != 0ull;
+  return xy;
+}
+
+__device__ __forceinline__ void page_mark(const RenderArgs& a, const PageEnv& pe, int lane, int xy, uint32_t* win, uint32_t* dirty) {
+  const int row_bytes = 9 * a.pad_w;  // one image row
+  const int lo = pe.lo, hi = pe.lo + 4096;
+  const uint32_t* mcells = reinterpret_cast<const uint32_t*>(a.blob + pe.h->base + pe.h->off_mcells);
+  for (int m0 = 0; m0 < pe.n_mcells; m0 += PW_WAVE) {
+    const int m = m0 + lane;
+    const uint32_t c = m < pe.n_mcells ? mcells[m] : 0u;
+    const int obj = c >> 24;
+    const int p = __shfl(xy, obj, PW_WAVE);
+    const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
+    const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
+    const int q0 = 3 * y * a.pad_w + x + pe.c0;
+    const int b00 = 9 * q0 + pe.shift_bytes;  // first byte of the cell's top sub-row
+    if (m >= pe.n_mcells || static_cast<unsigned>(x) >= static_cast<unsigned>(pe.W) ||
+        static_cast<unsigned>(y) >= static_cast<unsigned>(pe.H) || b00 >= hi || b00 + 2 * row_bytes + 9 <= lo)
+      continue;
+    const uint32_t kind = obj == 0 ? 3u : (obj <= pe.G ? 4u : 5u);
+    const uint32_t om = (c >> 16) & 0xffu;
+#pragma unroll
+    for (int zy = 0; zy < 3; zy++) {
+      const int q = q0 + zy * a.pad_w;
+      const int b0 = b00 + zy * row_bytes;
+      if (b0 + 9 <= lo || b0 >= hi) continue;
+      const uint32_t e = pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_entry_goal_bits(pe.estat[q]));
+      atomicMax(&win[q - pe.q_lo], (static_cast<uint32_t>(obj + 1) << 12) | e);
+      const int cl = max(b0 - lo, 0) >> 4, ch = min(b0 + 8 - lo, 4095) >> 4;
+      atomicOr(&dirty[cl >> 5], 1u << (cl & 31));
+      atomicOr(&dirty[ch >> 5], 1u << (ch & 31));
     }
   }
-  return e;
+}
+
+// the 16 bytes of chunk c (inside the environment's image) from the page's entry window + static table
+typedef unsigned int pw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pw_u32x4 page_chunk(const PageEnv& pe, int c, const uint32_t* win, const uint32_t* pal) {
+  const int bias_q = (pe.shift_bytes > 0 ? pe.shift_bytes / 9 : 0) + 2;
+  const unsigned o3 = static_cast<unsigned>(c * 16 - pe.shift_bytes + 9 * bias_q);
+  const unsigned qb = o3 / 9u;
+  const int b = static_cast<int>(o3 - qb * 9u);
+  const int q0 = static_cast<int>(qb) - bias_q;
+  uint32_t e0, e1, e2;
+  {
+    const uint32_t w0 = win[q0 - pe.q_lo], w1 = win[q0 + 1 - pe.q_lo], w2 = win[q0 + 2 - pe.q_lo];
+    e0 = w0 ? (w0 & 0xFFFu) : ((static_cast<unsigned>(q0) < static_cast<unsigned>(pe.n_entries)) ? pe.estat[q0] : 0u);
+    e1 = w1 ? (w1 & 0xFFFu) : ((static_cast<unsigned>(q0 + 1) < static_cast<unsigned>(pe.n_entries)) ? pe.estat[q0 + 1] : 0u);
+    e2 = w2 ? (w2 & 0xFFFu) : ((static_cast<unsigned>(q0 + 2) < static_cast<unsigned>(pe.n_entries)) ? pe.estat[q0 + 2] : 0u);
+  }
+  const uint32_t r00 = pal[e0 & 15u], r01 = pal[(e0 >> 4) & 15u], r02 = pal[(e0 >> 8) & 15u];
+  const uint32_t r10 = pal[e1 & 15u], r11 = pal[(e1 >> 4) & 15u], r12 = pal[(e1 >> 8) & 15u];
+  const uint32_t r20 = pal[e2 & 15u], r21 = pal[(e2 >> 4) & 15u];
+  const uint32_t d0 = r00 | (r01 << 24);
+  const uint32_t d1 = (r01 >> 8) | (r02 << 16);
+  const uint32_t d2 = (r02 >> 16) | (r10 << 8);
+  const uint32_t d3 = r11 | (r12 << 24);
+  const uint32_t d4 = (r12 >> 8) | (r20 << 16);
+  const uint32_t d5 = (r20 >> 16) | (r21 << 8);
+  const int sel = b >> 2;
+  const uint32_t s0 = sel == 0 ? d0 : (sel == 1 ? d1 : d2);
+  const uint32_t s1 = sel == 0 ? d1 : (sel == 1 ? d2 : d3);
+  const uint32_t s2 = sel == 0 ? d2 : (sel == 1 ? d3 : d4);
+  const uint32_t s3 = sel == 0 ? d3 : (sel == 1 ? d4 : d5);
+  const uint32_t s4 = sel == 0 ? d4 : d5;
+  const uint32_t bs = static_cast<uint32_t>(b & 3);
+  return pw_u32x4{__builtin_amdgcn_alignbyte(s1, s0, bs), __builtin_amdgcn_alignbyte(s2, s1, bs),
+                  __builtin_amdgcn_alignbyte(s3, s2, bs), __builtin_amdgcn_alignbyte(s4, s3, bs)};
 }
 
 __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyArgs ca) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef pw_u32x4 u32x4;
   __shared__ uint32_t pal[16];
   __shared__ uint32_t dirty[8];
-  __shared__ uint32_t n_items_s;
-  __shared__ uint32_t items[PW_PAGE_ITEMS];
+  __shared__ __align__(16) uint32_t win0[PW_PAGE_ENTRIES];
+  __shared__ __align__(16) uint32_t win1[PW_PAGE_ENTRIES];
   const int lane = threadIdx.x;
 
-  // ---- workgroup-uniform bookkeeping (scalar unit) -------------------------------------------
+  // ---- workgroup-uniform bookkeeping -------------------------------------------------------------
   const uint32_t g0 = blockIdx.x * 256u;  // first 16-byte chunk of the page
   const uint32_t cpe = ca.chunks_per_env;
-  const uint32_t env0 = g0 / cpe;
+  // g0 / cpe without an integer division: float estimate (exact to +-1 for g0 < 2^31) + correction
+  uint32_t env0 = static_cast<uint32_t>(static_cast<float>(g0) * ca.inv_cpe);
+  {
+    const int rr = static_cast<int>(g0 - env0 * cpe);
+    if (rr < 0) env0 -= 1u;
+    else if (rr >= static_cast<int>(cpe)) env0 += 1u;
+  }
+  env0 = __builtin_amdgcn_readfirstlane(env0);
   const uint32_t last = static_cast<uint32_t>(a.batch) - 1u;
-  const int split = static_cast<int>((env0 + 1u) * cpe - g0);  // local chunk where the next env starts (>= 1)
-  const bool has_second = split < 256 && env0 + 1u <= last;
+  const int c_first = static_cast<int>(g0 - env0 * cpe);  // chunk index of the page start inside env0
   const int pid0 = a.puzzle_id[env0];
+  uint8_t* dst = a.obs + static_cast<int64_t>(g0) * 16 + lane * 16;
+
+  if (c_first + 256 <= static_cast<int>(ca.n_chunks)) {
+    // ---- 13 of 14 pages: the whole page lies inside one environment's image ----------------------
+    const uint8_t* src = ca.simg + static_cast<int64_t>(pid0) * ca.simg_stride + static_cast<int64_t>(c_first) * 16 + lane * 16;
+    u32x4 v0 = *reinterpret_cast<const u32x4*>(src);
+    u32x4 v1 = *reinterpret_cast<const u32x4*>(src + 1024);
+    u32x4 v2 = *reinterpret_cast<const u32x4*>(src + 2048);
+    u32x4 v3 = *reinterpret_cast<const u32x4*>(src + 3072);
+    const PageEnv pe = page_env(a, pid0, env0, c_first * 16);
+    bool any;
+    const int xy = page_prefilter(a, pe, lane, any);
+    if (any) {  // ~40 % of the pages: some movable's rows cross this page
+      if (lane < 16) pal[lane] = a.pal_rgb[lane];
+      if (lane < 8) dirty[lane] = 0;
+      for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+      page_mark(a, pe, lane, xy, win0, dirty);
+      __syncthreads();
+      if (dirty[0] | dirty[1] | dirty[2] | dirty[3] | dirty[4] | dirty[5] | dirty[6] | dirty[7]) {
+        const int bit = lane & 31, wsel = lane >> 5;
+        if ((dirty[0 + wsel] >> bit) & 1u) v0 = page_chunk(pe, c_first + lane, win0, pal);
+        if ((dirty[2 + wsel] >> bit) & 1u) v1 = page_chunk(pe, c_first + lane + 64, win0, pal);
+        if ((dirty[4 + wsel] >> bit) & 1u) v2 = page_chunk(pe, c_first + lane + 128, win0, pal);
+        if ((dirty[6 + wsel] >> bit) & 1u) v3 = page_chunk(pe, c_first + lane + 192, win0, pal);
+      }
+    }
+    __builtin_nontemporal_store(v0, reinterpret_cast<u32x4*>(dst));
+    __builtin_nontemporal_store(v1, reinterpret_cast<u32x4*>(dst + 1024));
+    __builtin_nontemporal_store(v2, reinterpret_cast<u32x4*>(dst + 2048));
+    __builtin_nontemporal_store(v3, reinterpret_cast<u32x4*>(dst + 3072));
+    return;
+  }
+
+  // ---- the page holds the tail of env0 (and usually the head of env0 + 1) ------------------------
+  const int split = static_cast<int>(cpe) - c_first;  // local chunk where the next environment starts
+  const bool has_second = split < 256 && env0 + 1u <= last;
   const int pid1 = a.puzzle_id[min(env0 + 1u, last)];
-  const int c_first = static_cast<int>(g0 - env0 * cpe);       // chunk index of the page start inside env0
   const int valid0 = static_cast<int>(ca.n_chunks) - c_first;  // local chunks [0, valid0) of env0 carry image bytes
   const uint8_t* src0 = ca.simg + static_cast<int64_t>(pid0) * ca.simg_stride + static_cast<int64_t>(c_first) * 16;
   const uint8_t* src1 = ca.simg + static_cast<int64_t>(pid1) * ca.simg_stride - static_cast<int64_t>(split) * 16;
-  uint8_t* dst = a.obs + static_cast<int64_t>(g0) * 16;
-
-  // ---- clean path: static-image loads go out first --------------------------------------------
-  u32x4 v[4];
-  bool ok[4];
-#pragma unroll
+  if (lane < 16) pal[lane] = a.pal_rgb[lane];
+  if (lane < 8) dirty[lane] = 0;
+  for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) {
+    reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(win1)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  const PageEnv pe0 = page_env(a, pid0, env0, c_first * 16);
+  const PageEnv pe1 = page_env(a, pid1, env0 + 1u, -split * 16);
+  bool any0, any1 = false;
+  const int xy0 = page_prefilter(a, pe0, lane, any0);
+  if (any0) page_mark(a, pe0, lane, xy0, win0, dirty);
+  if (has_second) {
+    const int xy1 = page_prefilter(a, pe1, lane, any1);
+    if (any1) page_mark(a, pe1, lane, xy1, win1, dirty);
+  }
+  __syncthreads();
+#pragma unroll 1
   for (int k = 0; k < 4; k++) {
     const int lc = lane + 64 * k;
     const bool second = lc >= split;
-    ok[k] = second ? (has_second && lc - split < static_cast<int>(ca.n_chunks)) : (lc < valid0);
-    const uint8_t* src = (second ? src1 : src0) + lc * 16;
-    v[k] = u32x4{0u, 0u, 0u, 0u};
-    if (ok[k]) v[k] = *reinterpret_cast<const u32x4*>(src);
-  }
-
-  // ---- which movable cells reach into this page? ------------------------------------------------
-  if (lane < 8) dirty[lane] = 0;
-  if (lane == 8) n_items_s = 0;
-  bool any_items = false;
-  const int wpx = a.pad_w * 3;
-  const int row_bytes = 9 * a.pad_w;  // one image row
-  for (int es = 0; es < (has_second ? 2 : 1); es++) {
-    const PwPuzzleHeader* h = a.hdrs + (es ? pid1 : pid0);
-    const int W = h->W, H = h->H, N = h->N;
-    const int pady = (a.pad_h - H) * 3 / 2;
-    const int padx = (a.pad_w - W) * 3 / 2;
-    const int c0 = (padx + 2) / 3;
-    const int shift_bytes = 3 * (pady * wpx + padx - 3 * c0);
-    // byte range of the page inside this environment's image (negative lo for the second env)
-    const int lo = es ? -split * 16 : c_first * 16;
-    const int hi = lo + 4096;
-    // bounding-box prefilter, one lane per object: rows [3y, 3(y+h)) of the image
-    int xy = 0;
-    bool hit = false;
-    if (lane < N) {
-      xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env0 + es) * a.np + lane]);
-      const int y = static_cast<int8_t>((xy >> 8) & 0xff);
-      const int hh = h->objtab[lane].h;
-      const int first = 3 * y * row_bytes + shift_bytes, end = 3 * (y + hh) * row_bytes + shift_bytes + 9;
-      hit = first < hi && end > lo;
-    }
-    if (__ballot(hit) == 0ull) continue;  // most pages: nothing moves here
-    if (!any_items) {
-      any_items = true;
-      __syncthreads();  // LDS init above is visible
-    }
-    const int G = h->G, n_mcells = static_cast<int>(h->n_mcells);
-    const uint32_t* mcells = reinterpret_cast<const uint32_t*>(a.blob + h->base + h->off_mcells);
-    const uint16_t* estat = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[es ? pid1 : pid0]);
-    for (int m0 = 0; m0 < n_mcells; m0 += PW_WAVE) {
-      const int m = m0 + lane;
-      const uint32_t c = m < n_mcells ? mcells[m] : 0u;
-      const int obj = c >> 24;
-      const int p = __shfl(xy, obj, PW_WAVE);
-      const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
-      const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
-      const int q0 = 3 * y * a.pad_w + x + c0;
-      const int b00 = 9 * q0 + shift_bytes;  // first byte of the cell's top sub-row
-      if (m >= n_mcells || static_cast<unsigned>(x) >= static_cast<unsigned>(W) || static_cast<unsigned>(y) >= static_cast<unsigned>(H) ||
-          b00 >= hi || b00 + 2 * row_bytes + 9 <= lo)
-        continue;
-      const uint32_t kind = obj == 0 ? 3u : (obj <= G ? 4u : 5u);
-      const uint32_t om = (c >> 16) & 0xffu;
-#pragma unroll
-      for (int zy = 0; zy < 3; zy++) {
-        const int q = q0 + zy * a.pad_w;
-        const int b0 = b00 + zy * row_bytes;
-        if (b0 + 9 <= lo || b0 >= hi) continue;
-        const uint32_t e = pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_entry_goal_bits(estat[q]));
-        const uint32_t slot = atomicAdd(&n_items_s, 1u);
-        if (slot < PW_PAGE_ITEMS) items[slot] = e | (static_cast<uint32_t>(obj) << 12) | (static_cast<uint32_t>(q) << 17) | (static_cast<uint32_t>(es) << 30);
-        const int cl = max(b0 - lo, 0) >> 4, ch = min(b0 + 8 - lo, 4095) >> 4;
-        atomicOr(&dirty[cl >> 5], 1u << (cl & 31));
-        atomicOr(&dirty[ch >> 5], 1u << (ch & 31));
-      }
-    }
-  }
-
-  if (any_items) {
-    if (lane < 16) pal[lane] = a.pal_rgb[lane];
-    __syncthreads();
-    const uint32_t n_items_all = n_items_s;
-    const int n_items = static_cast<int>(min(n_items_all, static_cast<uint32_t>(PW_PAGE_ITEMS)));
-    if (n_items_all != 0u) {
-#pragma unroll 1
-      for (int k = 0; k < 4; k++) {
-        const int lc = lane + 64 * k;  // chunk inside the page
-        const bool is_dirty = n_items_all > PW_PAGE_ITEMS || ((dirty[lc >> 5] >> (lc & 31)) & 1u);
-        if (!ok[k] || !is_dirty) continue;
-        const int es = lc >= split ? 1 : 0;
-        const uint32_t env = env0 + es;
-        const int c = es ? lc - split : c_first + lc;
-        const int pid = es ? pid1 : pid0;
-        const PwPuzzleHeader* h = a.hdrs + pid;
-        const int W = h->W, H = h->H;
-        const uint16_t* estat = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[pid]);
-        const int pady = (a.pad_h - H) * 3 / 2;
-        const int padx = (a.pad_w - W) * 3 / 2;
-        const int c0 = (padx + 2) / 3;
-        const int shift_bytes = 3 * (pady * wpx + padx - 3 * c0);
-        const int n_entries = 3 * H * a.pad_w;
-        const int bias_q = (shift_bytes > 0 ? shift_bytes / 9 : 0) + 2;
-        const unsigned o3 = static_cast<unsigned>(c * 16 - shift_bytes + 9 * bias_q);
-        const unsigned qb = o3 / 9u;
-        const int b = static_cast<int>(o3 - qb * 9u);
-        const int q0 = static_cast<int>(qb) - bias_q;
-        uint32_t ee[3];
-        if (n_items_all > PW_PAGE_ITEMS) {
-          // list overflow (only possible with many overlapping movables): rescan the cell list
-          const uint32_t* mcells = reinterpret_cast<const uint32_t*>(a.blob + h->base + h->off_mcells);
-          for (int t = 0; t < 3; t++) {
-            const int q = q0 + t;
-            uint32_t e = (static_cast<unsigned>(q) < static_cast<unsigned>(n_entries)) ? estat[q] : 0u;
-            int best = -1;
-            for (int m = 0; m < static_cast<int>(h->n_mcells); m++) {
-              const uint32_t cc = mcells[m];
-              const int obj = cc >> 24;
-              const int pp = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + obj]);
-              const int x = static_cast<int8_t>(pp & 0xff) + static_cast<int>(cc & 0xff);
-              const int y = static_cast<int8_t>((pp >> 8) & 0xff) + static_cast<int>((cc >> 8) & 0xff);
-              if (static_cast<unsigned>(x) >= static_cast<unsigned>(W) || static_cast<unsigned>(y) >= static_cast<unsigned>(H)) continue;
-              for (int zy = 0; zy < 3; zy++)
-                if ((3 * y + zy) * a.pad_w + x + c0 == q && obj > best) {
-                  best = obj;
-                  const uint32_t kind = obj == 0 ? 3u : (obj <= h->G ? 4u : 5u);
-                  e = pw_zone_entry(kind, pw_zone_border_bits((cc >> 16) & 0xffu, zy), pw_entry_goal_bits(estat[q]));
-                }
-            }
-            ee[t] = e;
-          }
-        } else {
-          for (int t = 0; t < 3; t++) ee[t] = page_entry(items, n_items, estat, n_entries, q0 + t, es);
-        }
-        const uint32_t e0 = ee[0], e1 = ee[1], e2 = ee[2];
-        const uint32_t r00 = pal[e0 & 15u], r01 = pal[(e0 >> 4) & 15u], r02 = pal[(e0 >> 8) & 15u];
-        const uint32_t r10 = pal[e1 & 15u], r11 = pal[(e1 >> 4) & 15u], r12 = pal[(e1 >> 8) & 15u];
-        const uint32_t r20 = pal[e2 & 15u], r21 = pal[(e2 >> 4) & 15u];
-        const uint32_t d0 = r00 | (r01 << 24);
-        const uint32_t d1 = (r01 >> 8) | (r02 << 16);
-        const uint32_t d2 = (r02 >> 16) | (r10 << 8);
-        const uint32_t d3 = r11 | (r12 << 24);
-        const uint32_t d4 = (r12 >> 8) | (r20 << 16);
-        const uint32_t d5 = (r20 >> 16) | (r21 << 8);
-        const int sel = b >> 2;
-        const uint32_t s0 = sel == 0 ? d0 : (sel == 1 ? d1 : d2);
-        const uint32_t s1 = sel == 0 ? d1 : (sel == 1 ? d2 : d3);
-        const uint32_t s2 = sel == 0 ? d2 : (sel == 1 ? d3 : d4);
-        const uint32_t s3 = sel == 0 ? d3 : (sel == 1 ? d4 : d5);
-        const uint32_t s4 = sel == 0 ? d4 : d5;
-        const uint32_t bs = static_cast<uint32_t>(b & 3);
-        const u32x4 nv = {__builtin_amdgcn_alignbyte(s1, s0, bs), __builtin_amdgcn_alignbyte(s2, s1, bs),
-                          __builtin_amdgcn_alignbyte(s3, s2, bs), __builtin_amdgcn_alignbyte(s4, s3, bs)};
-        if (k == 0) v[0] = nv;
-        else if (k == 1) v[1] = nv;
-        else if (k == 2) v[2] = nv;
-        else v[3] = nv;
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int lc = lane + 64 * k;
-    if (ok[k]) __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(dst + lc * 16));
+    const bool ok = second ? (has_second && lc - split < static_cast<int>(ca.n_chunks)) : (lc < valid0);
+    if (!ok) continue;
+    u32x4 v;
+    if ((dirty[lc >> 5] >> (lc & 31)) & 1u)
+      v = second ? page_chunk(pe1, lc - split, win1, pal) : page_chunk(pe0, c_first + lc, win0, pal);
+    else
+      v = *reinterpret_cast<const u32x4*>((second ? src1 : src0) + lc * 16);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + k * 1024));
   }
 }
 
@@ -1959,10 +1967,11 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   e->max_mcells = 0;
   for (int p = 0; p < s->count; p++) e->max_mcells = std::max(e->max_mcells, static_cast<int32_t>(s->headers[p].n_mcells));
   if (3 * e->max_mcells > PW_OV_HASH * 3 / 4) e->overlay_render = false;  // hash table too small: LDS kernel
-  const bool page_path = rsel && (std::string(rsel) == "copy" || std::string(rsel) == "page" || e->overlay_render);
-  // The page-ordered paths (PUSHWORLD_AMD_RENDER=page|copy) are correct but not yet faster than the
-  // per-environment LDS kernel; they are opt-in.
-  const bool want_copy = e->fast_u8_ppc3 && page_path &&
+  // Default for uint8 / ppc 3: the page-ordered kernel (static-image copy + LDS entry window), as long
+  // as the static images of the whole puzzle set stay cache resident (64 MB; they are read once per
+  // observation).  PUSHWORLD_AMD_RENDER=lds|page|copy|overlay selects a path explicitly.
+  const bool want_lds = rsel && std::string(rsel) == "lds";
+  const bool want_copy = e->fast_u8_ppc3 && !want_lds &&
                          static_cast<int64_t>(s->count) * e->simg_stride <= (int64_t(64) << 20);
   if (err == hipSuccess && want_copy) {
     int32_t* d_ids = nullptr;
@@ -2017,6 +2026,24 @@ int pw_engine_obs_shape(const PwEngine* e, int* h, int* w, int* c) {
   if (w) *w = e->obs_w;
   if (c) *c = 3;
   return PW_OK;
+}
+
+int pw_engine_render_kernel(const PwEngine* e, char* buf, int cap) {
+  if (!e) return pw_fail(PW_EINVAL, "null engine");
+  const char* name = "pw_render_generic_kernel";
+  if (e->fast_u8_ppc3) {
+    if (!e->d_simg) name = "pw_render_u8_ppc3_kernel";
+    else if (e->overlay_render) name = "pw_render_ovl_kernel";
+    else if (e->two_pass_render) name = "pw_render_copy_kernel";
+    else name = "pw_render_page_kernel";
+  }
+  const int n = static_cast<int>(strlen(name));
+  if (buf && cap > 0) {
+    const int m = n < cap - 1 ? n : cap - 1;
+    memcpy(buf, name, m);
+    buf[m] = 0;
+  }
+  return n;
 }
 
 int64_t pw_engine_obs_bytes(const PwEngine* e) { return e ? e->obs_bytes : pw_fail(PW_EINVAL, "null engine"); }
