@@ -2077,7 +2077,9 @@ static int fill_step_args(PwEngine* e, const int32_t* puzzle_id, const uint8_t* 
 }
 
 static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipStream_t st) {
-  if (e->d_simg && !ra.do_step && !ra.skip_movables) {
+  // page kernels: a 4 KiB page may hold the tail of one environment and the head of the next, not
+  // more -- observations smaller than a page take the per-environment LDS kernel
+  if (e->d_simg && !ra.do_step && !ra.skip_movables && ra.env_stride >= 4096) {
     CopyArgs ca;
     ca.simg = e->d_simg;
     ca.puzzle_id = ra.puzzle_id;

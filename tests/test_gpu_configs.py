@@ -198,3 +198,74 @@ def test_c4_full_mix_shard(golden):
             assert tuple(map(tuple, pos[b, : oz.num_movables].tolist())) == s and rr[b] == rew and bool(tt[b]) == term
             if k % 8 == 0:
                 assert (obs[b].cpu().numpy() == oz.observation(s, 54, 47, 3, 1, dtype="u8")).all(), (t, b)
+
+
+@pytest.mark.parametrize("ppc,obs", [(3, "uint8"), (4, "uint8"), (3, "float32")])
+def test_small_frames_many_envs(golden, ppc, obs):
+    """Level-0 puzzles in their own (small) frame: observations of 1.3-3.9 KB, i.e. several
+    environments per 4 KiB page of the buffer.  Every environment's observation equals the
+    oracle's along a random walk."""
+    import torch
+
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith("l0:")][::6]
+    texts = [golden.text(k) for k in keys]
+    pool = [PushWorldPuzzle(text=t) for t in texts]
+    oracles = [c_oracle.COraclePuzzle(t) for t in texts]
+    B = 3 * len(pool)
+    ids = np.arange(B) % len(pool)
+    vec = VecPushWorld(pool, B, puzzle_ids=ids, pixels_per_cell=ppc, border_width=1, observation=obs, device=0)
+    fh, fw = vec.engine.obs_shape[0] // ppc, vec.engine.obs_shape[1] // ppc
+    assert vec.engine.obs_bytes < 4096 * (4 if obs == "float32" else 1) * (2 if ppc == 4 else 1)
+    vec.reset()
+    gen = torch.Generator(device=vec.device)
+    gen.manual_seed(9)
+    acts = torch.randint(0, 4, (30, B), generator=gen, device=vec.device, dtype=torch.uint8)
+    acts_h = acts.cpu().numpy()
+    states = [oracles[i].initial_state for i in ids]
+    for t in range(30):
+        o = vec.step(acts[t])[0]
+        for b in range(B):
+            states[b] = oracles[ids[b]].get_next_state(states[b], int(acts_h[t, b]))
+        if t % 7 == 0 or t == 29:
+            img = o.cpu().numpy()
+            for b in range(B):
+                want = oracles[ids[b]].observation(states[b], fh, fw, ppc, 1, dtype="u8" if obs == "uint8" else "f32")
+                assert (img[b] == want).all(), (t, b)
+
+
+def test_frames_just_above_one_page(golden):
+    """Observation of 5.8 KB (frame 18x12 cells): every 4 KiB page of the buffer straddles two
+    environments, the code path of the page-ordered render kernel that the C3 frame exercises
+    only once per environment."""
+    import torch
+
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith("pytest:")]
+    texts = [golden.text(k) for k in keys]
+    pool = [PushWorldPuzzle(text=t) for t in texts]
+    oracles = [c_oracle.COraclePuzzle(t) for t in texts]
+    B = 37 * len(pool)
+    ids = np.sort(np.arange(B) % len(pool))
+    vec = VecPushWorld(pool, B, puzzle_ids=ids, pixels_per_cell=3, border_width=1, observation="uint8", device=0)
+    assert vec.engine.render_kernel == "pw_render_page_kernel" and vec.engine.obs_shape == (54, 36, 3)
+    vec.reset()
+    gen = torch.Generator(device=vec.device)
+    gen.manual_seed(11)
+    acts = torch.randint(0, 4, (40, B), generator=gen, device=vec.device, dtype=torch.uint8)
+    acts_h = acts.cpu().numpy()
+    states = [oracles[i].initial_state for i in ids]
+    for t in range(40):
+        o = vec.step(acts[t])[0]
+        for b in range(B):
+            states[b] = oracles[ids[b]].get_next_state(states[b], int(acts_h[t, b]))
+        if t % 13 == 0 or t == 39:
+            img = o.cpu().numpy()
+            for b in range(B):
+                assert (img[b] == oracles[ids[b]].observation(states[b], 18, 12, 3, 1, dtype="u8")).all(), (t, b)
