@@ -83,7 +83,8 @@ def main():
     ap.add_argument("--obs", choices=["uint8", "float32", "none"], default="uint8")
     ap.add_argument("--max-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused", type=int, default=0, help="1: pw_step_render single launch; 0: pw_step + pw_render")
+    ap.add_argument("--fused", type=int, default=0,
+                    help="0: pw_step then pw_render (events bracket the render kernel); 1: one pw_step_render call")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

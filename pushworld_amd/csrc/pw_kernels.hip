@@ -44,6 +44,7 @@ struct PwEngine {
   size_t render_lds;
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
   int step_kernel;         // 0 group (default), 1 wavefront per env, 2 lane per env (PUSHWORLD_AMD_STEP)
+  bool force_fused;        // PUSHWORLD_AMD_FUSED=1: pw_step_render always uses the single fused launch
   bool two_pass_render;    // PUSHWORLD_AMD_RENDER=copy: copy kernel + patch kernel instead of the page kernel
   bool overlay_render;     // PUSHWORLD_AMD_RENDER=overlay: mark kernel + page-ordered overlay kernel
   uint8_t* d_overlay;      // per-environment overlay records (grown on demand)
@@ -1898,6 +1899,8 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   {
     const char* sel = getenv("PUSHWORLD_AMD_STEP");
     e->step_kernel = (sel && std::string(sel) == "wave") ? 1 : ((sel && std::string(sel) == "lane") ? 2 : 0);
+    const char* ff = getenv("PUSHWORLD_AMD_FUSED");
+    e->force_fused = ff && std::string(ff) == "1";
   }
   // Static zone-colour tables (walls, agent walls, background, goal outlines) of every puzzle in
   // the layout the render kernel of this engine streams from: row stride pad_w with the puzzle
@@ -2210,8 +2213,10 @@ int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* ob
   return check_launch("pw_render");
 }
 
-// One launch: wave 0 of every workgroup advances its environment (pw_step semantics), the
-// whole workgroup then draws the new state.
+// Step + observation.  With the page-ordered render the step kernel and the render kernel are two
+// launches on the caller's stream (splitting the batch over two streams to hide the 26 us step
+// kernel behind the render of the other half measured 2 % SLOWER); otherwise ONE launch: wave 0
+// of every per-environment workgroup advances its environment, the workgroup then draws it.
 int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,
                    double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, void* obs,
                    int64_t env_stride_bytes, int32_t batch, uint32_t flags, void* stream) {
@@ -2224,9 +2229,21 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
   const StepArgs sa = ra.step;
   rc = fill_render_args(e, puzzle_id, pos, obs, env_stride_bytes, batch, &ra);
   if (rc != PW_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (e->d_simg && env_stride_bytes >= 4096 && !e->force_fused) {
+    RolloutArgs r;
+    r.s = sa;
+    r.num_steps = 1;
+    r.reward_hist = nullptr;
+    r.term_hist = nullptr;
+    r.trunc_hist = nullptr;
+    launch_group(e, r, batch, st);
+    launch_render(e, ra, batch, st);
+    return check_launch("pw_step_render");
+  }
   ra.step = sa;
   ra.do_step = 1;
-  launch_render(e, ra, batch, static_cast<hipStream_t>(stream));
+  launch_render(e, ra, batch, st);
   return check_launch("pw_step_render");
 }
 

@@ -33,8 +33,8 @@ class VecPushWorld:
         pad_cells: (height, width) of the observation frame in cells; default = pool maximum
             (gym_env.py:80-82).
         autoreset: next-step autoreset inside the step kernel.
-        fused: step and render in ONE launch (``pw_step_render``) instead of the lane-per-env step
-            kernel followed by the render kernel.
+        fused: one ``pw_step_render`` call per step (the library picks the schedule: step kernel +
+            page-ordered render, or a single fused launch) instead of ``pw_step`` + ``pw_render``.
     """
 
     def __init__(self, puzzles: Sequence[Union[str, PushWorldPuzzle]], num_envs: int,

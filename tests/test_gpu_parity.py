@@ -233,11 +233,14 @@ def test_alternative_render_paths_match_lds_kernel(golden, torch_mod, path, monk
     assert torch.equal(ref.render(), alt.render())
 
 
-def test_fused_step_render_matches_reference(golden, puzzles, torch_mod):
-    """pw_step_render (ONE launch: step in wave 0 + render) on a mixed batch: states, rewards,
+@pytest.mark.parametrize("force_fused", ["1", "0"])
+def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_fused, monkeypatch):
+    """pw_step_render on a mixed batch, both schedules (PUSHWORLD_AMD_FUSED=1: ONE launch, step in
+    wave 0 + per-environment render; 0: step kernel + page-ordered render): states, rewards,
     flags equal the golden trajectories and the observation equals the oracle's image of the
     reference state at every checked step (uint8, ppc 3, frame = batch maximum)."""
     torch = torch_mod
+    monkeypatch.setenv("PUSHWORLD_AMD_FUSED", force_fused)
     from oracle import c_oracle
     from pushworld_amd.vec_env import VecPushWorld
 
