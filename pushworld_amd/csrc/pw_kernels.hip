@@ -1272,20 +1272,25 @@ __device__ __forceinline__ PageEnv page_env(const RenderArgs& a, int pid, uint32
 // into the page's LDS entry window `win` (atomicMax on (object + 1) << 12 | entry: the highest
 // object index wins = painter order, puzzle.py:457) and the chunks they touch are marked in
 // `dirty`.  page_prefilter() tells beforehand whether any object's rows meet the page at all.
-// lane j < N: packed position of movable j; `any` = some movable's rows meet the page
-__device__ __forceinline__ int page_prefilter(const RenderArgs& a, const PageEnv& pe, int lane, bool& any) {
+// packed positions of an environment's movables, lane j = movable j (zero padding beyond N); needs
+// no puzzle data, so it is issued before the puzzle id is known
+__device__ __forceinline__ int page_load_xy(const RenderArgs& a, uint32_t env, int lane) {
+  int xy = 0;
+  if (lane < a.np) xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + lane]);
+  return xy;
+}
+
+// `any` = some movable's rows meet the page
+__device__ __forceinline__ bool page_prefilter(const RenderArgs& a, const PageEnv& pe, int lane, int xy) {
   const int row_bytes = 9 * a.pad_w;  // one image row
   const int lo = pe.lo, hi = pe.lo + 4096;
-  int xy = 0;
   bool hit = false;
   if (lane < pe.N) {
-    xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(pe.env) * a.np + lane]);
     const int y = static_cast<int8_t>((xy >> 8) & 0xff);
     const int hh = pe.h->objtab[lane].h;
     hit = 3 * y * row_bytes + pe.shift_bytes < hi && 3 * (y + hh) * row_bytes + pe.shift_bytes + 9 > lo;
   }
-  any = __ballot(hit) != 0ull;
-  return xy;
+  return __ballot(hit) != 0ull;
 }
 
 __device__ __forceinline__ void page_mark(const RenderArgs& a, const PageEnv& pe, int lane, int xy, uint32_t* win, uint32_t* dirty) {
@@ -1376,6 +1381,7 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
   env0 = __builtin_amdgcn_readfirstlane(env0);
   const uint32_t last = static_cast<uint32_t>(a.batch) - 1u;
   const int c_first = static_cast<int>(g0 - env0 * cpe);  // chunk index of the page start inside env0
+  const int xy0 = page_load_xy(a, env0, lane);             // independent of the puzzle: issued first
   const int pid0 = a.puzzle_id[env0];
   uint8_t* dst = a.obs + static_cast<int64_t>(g0) * 16 + lane * 16;
 
@@ -1387,9 +1393,8 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
     u32x4 v2 = *reinterpret_cast<const u32x4*>(src + 2048);
     u32x4 v3 = *reinterpret_cast<const u32x4*>(src + 3072);
     const PageEnv pe = page_env(a, pid0, env0, c_first * 16);
-    bool any;
-    const int xy = page_prefilter(a, pe, lane, any);
-    if (any) {  // ~40 % of the pages: some movable's rows cross this page
+    const int xy = xy0;
+    if (page_prefilter(a, pe, lane, xy)) {  // ~40 % of the pages: some movable's rows cross this page
       if (lane < 16) pal[lane] = a.pal_rgb[lane];
       if (lane < 8) dirty[lane] = 0;
       for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1427,12 +1432,10 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
   __syncthreads();
   const PageEnv pe0 = page_env(a, pid0, env0, c_first * 16);
   const PageEnv pe1 = page_env(a, pid1, env0 + 1u, -split * 16);
-  bool any0, any1 = false;
-  const int xy0 = page_prefilter(a, pe0, lane, any0);
-  if (any0) page_mark(a, pe0, lane, xy0, win0, dirty);
+  if (page_prefilter(a, pe0, lane, xy0)) page_mark(a, pe0, lane, xy0, win0, dirty);
   if (has_second) {
-    const int xy1 = page_prefilter(a, pe1, lane, any1);
-    if (any1) page_mark(a, pe1, lane, xy1, win1, dirty);
+    const int xy1 = page_load_xy(a, env0 + 1u, lane);
+    if (page_prefilter(a, pe1, lane, xy1)) page_mark(a, pe1, lane, xy1, win1, dirty);
   }
   __syncthreads();
 #pragma unroll 1
