@@ -37,6 +37,8 @@ class GoldenData:
 
     def text(self, key: str) -> str:
         kind, rel = key.split(":", 1)
+        if kind == "rand":
+            return self.meta[key]["text"]
         if kind == "bench":
             with open(os.path.join(DATA, "puzzles", rel)) as f:
                 return f.read()

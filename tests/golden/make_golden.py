@@ -25,6 +25,7 @@ Puzzle keys are paths relative to the vendored data roots:
   ``l0:<zip member>``               pushworld_amd/data/puzzles/level0.zip
   ``pytest:<name>.pwp``             tests/puzzles/ref_python
   ``cpptest:<name>.pwp``            tests/puzzles/ref_cpp
+  ``rand:<i>``                      random puzzles generated here (text stored in golden_meta.json)
 """
 import hashlib
 import json
@@ -50,6 +51,7 @@ PADS = {"own": None, "l1": (51, 42), "std": (54, 47)}  # (max_cell_height, max_c
 N_RANDOM_STEPS = 400
 N_L0_PER_FAMILY_TRAIN = 56
 N_L0_PER_FAMILY_TEST = 8
+N_RANDOM_PUZZLES = 160
 ACTION_CHARS = {"L": 0, "R": 1, "U": 2, "D": 3}
 
 
@@ -91,6 +93,74 @@ def collect_puzzles(tmpdir):
                     f.write(z.read(m))
                 out.append((f"l0:{m}", p))
     return out
+
+
+def random_puzzle_text(rng):
+    """A random small puzzle of this repository's own authorship: random walls / agent walls,
+    multi-cell (possibly disconnected) agent and movables, goals with ids >= 10 (string ordering),
+    '+' overlaps (movable on goal / agent wall / wall, agent on goal)."""
+    cols, rows = int(rng.integers(3, 15)), int(rng.integers(3, 13))
+    grid = [[set() for _ in range(cols)] for _ in range(rows)]
+
+    def free_cells(n, allow=()):
+        out = []
+        for _ in range(200):
+            if len(out) == n:
+                break
+            x, y = int(rng.integers(0, cols)), int(rng.integers(0, rows))
+            if all(t in allow for t in grid[y][x]) and (x, y) not in out:
+                out.append((x, y))
+        return out
+
+    def blob(n):
+        x, y = int(rng.integers(0, cols)), int(rng.integers(0, rows))
+        cells = [(x, y)]
+        for _ in range(n - 1):
+            bx, by = cells[int(rng.integers(0, len(cells)))]
+            dx, dy = [(1, 0), (-1, 0), (0, 1), (0, -1), (2, 0), (0, 2)][int(rng.integers(0, 6))]
+            nx, ny = bx + dx, by + dy
+            if 0 <= nx < cols and 0 <= ny < rows and (nx, ny) not in cells:
+                cells.append((nx, ny))
+        return cells
+
+    for (x, y) in free_cells(int(cols * rows * rng.uniform(0.0, 0.15))):
+        grid[y][x].add("W")
+    for (x, y) in free_cells(int(cols * rows * rng.uniform(0.0, 0.1))):
+        grid[y][x].add("AW")
+    placed = False
+    for _ in range(50):
+        cells = blob(int(rng.integers(1, 4)))
+        if all(not grid[y][x] for x, y in cells):
+            for x, y in cells:
+                grid[y][x].add("A")
+            placed = True
+            break
+    if not placed:
+        grid[0][0] = {"A"}
+    ids = list(rng.choice([0, 1, 2, 3, 7, 10, 11, 12, 20], size=int(rng.integers(1, 6)), replace=False))
+    for k in ids:
+        for _ in range(30):
+            cells = blob(int(rng.integers(1, 6)))
+            allow = ("AW",) if rng.random() < 0.5 else ()
+            if rng.random() < 0.05:
+                allow = ("AW", "W")
+            if all(all(t in allow for t in grid[y][x]) for x, y in cells):
+                for x, y in cells:
+                    grid[y][x].add(f"M{k}")
+                if rng.random() < 0.6:
+                    for (x, y) in blob(int(rng.integers(1, 4))):
+                        if not any(t.startswith("G") for t in grid[y][x]) and rng.random() < 0.9:
+                            grid[y][x].add(f"G{k}")
+                break
+    has_m = {t[1:] for row in grid for c in row for t in c if t.startswith("M")}
+    lines = []
+    for row in grid:
+        toks = []
+        for c in row:
+            c = {t for t in c if not (t.startswith("G") and t[1:] not in has_m)}
+            toks.append("+".join(sorted(c)) if c else ".")
+        lines.append(" ".join(f"{t:>6s}" for t in toks))
+    return "\n".join(lines) + "\n"
 
 
 def load_plan(key):
@@ -137,6 +207,21 @@ def main():
     images = {}
     with tempfile.TemporaryDirectory() as tmp:
         puzzles = collect_puzzles(tmp)
+        rand_text = {}
+        prng = np.random.default_rng(20260928)
+        n_rand = 0
+        while n_rand < N_RANDOM_PUZZLES:
+            text = random_puzzle_text(prng)
+            p = os.path.join(tmp, f"rand_{n_rand}.pwp")
+            with open(p, "w") as f:
+                f.write(text)
+            try:
+                PushWorldPuzzle(p)
+            except Exception:  # noqa: BLE001  (e.g. a goal whose movable could not be placed)
+                continue
+            rand_text[f"rand:{n_rand}"] = text
+            puzzles.append((f"rand:{n_rand}", p))
+            n_rand += 1
         for idx, (key, path) in enumerate(puzzles):
             pz = PushWorldPuzzle(path)
             n = pz.num_movables
@@ -220,6 +305,8 @@ def main():
                             ent[f"f32_{pname}"] = sha(obs)
                         rd.append(ent)
             m["renders"] = rd
+            if key in rand_text:
+                m["text"] = rand_text[key]
             meta[key] = m
 
             # random in-bounds states (may overlap): 4 successors each

@@ -147,7 +147,7 @@ def test_render_u8_digests(golden, puzzles, torch_mod, ppc, bw):
     from pushworld_amd import _capi
 
     n = 0
-    for k, ent in _render_cases(golden, ("bench:", "pytest:", "cpptest:", "l0:")):
+    for k, ent in _render_cases(golden, ("bench:", "pytest:", "cpptest:", "l0:", "rand:")):
         if ent["ppc"] != ppc or ent["bw"] != bw:
             continue
         img = puzzles[k].render([tuple(p) for p in ent["state"]], border_width=bw, pixels_per_cell=ppc)
@@ -166,7 +166,7 @@ def test_observation_f32_digests(golden, puzzles, torch_mod, ppc, bw, pad):
 
     pads = {"own": None, "l1": (51, 42), "std": (54, 47)}
     n = 0
-    for k, ent in _render_cases(golden, ("bench:", "pytest:")):
+    for k, ent in _render_cases(golden, ("bench:", "pytest:", "rand:")):
         if ent["ppc"] != ppc or ent["bw"] != bw or f"f32_{pad}" not in ent:
             continue
         if ppc == 20 and pad != "own" and (n % 7):  # 12 MB frames: sample
