@@ -138,6 +138,26 @@ int pw_reset(PwEngine* e, const int32_t* puzzle_id, const uint8_t* mask, int8_t*
              int32_t* steps, uint8_t* terminated, uint8_t* truncated, int32_t batch,
              void* stream);
 
+/* Episode management on the device (the batched counterpart of
+ * `self._current_puzzle = random.choice(self._puzzles)`, gym_env.py:172 / dm_env.py:172).
+ * Every environment whose terminated[e] | truncated[e] flag is set (either pointer may be NULL;
+ * both NULL = every environment) draws the puzzle of its next episode:
+ *     episode[e] += 1
+ *     r   = pw_mix64(seed, e, episode[e])          -- splitmix64 finaliser, see below
+ *     idx = floor(r * n / 2^64)                     -- n = table_len, or the set size without a table
+ *     puzzle_id[e] = table ? table[idx] : idx
+ * `table` (device int32 [table_len], NULL = uniform over the set) holds puzzle indices, repeated to
+ * weight them (e.g. the 50 % Level-0 / 50 % Level-1..4 mix of config C4).  The draw depends only on
+ * (seed, e, episode[e]), not on launch geometry.  Call it before a pw_step(PW_STEP_AUTORESET): that
+ * step then resets the finished environments to the initial state of their new puzzle.
+ *     pw_mix64: z = seed + 0x9E3779B97F4A7C15 * (e + 1) + 0xD1B54A32D192ED03 * episode  (mod 2^64)
+ *               z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;  z = (z ^ z >> 27) * 0x94D049BB133111EB;
+ *               r = z ^ z >> 31 */
+uint64_t pw_mix64(uint64_t seed, uint64_t env, uint64_t episode); /* host copy of the hash above */
+int pw_resample(PwEngine* e, int32_t* puzzle_id, const uint8_t* terminated, const uint8_t* truncated,
+                const int32_t* table, int32_t table_len, uint64_t seed, uint32_t* episode,
+                int32_t batch, void* stream);
+
 /* gym_env.py:188-226 step() without the observation:
  *   pos <- get_next_state(pos, action)                 puzzle.py:348-394
  *   terminated <- is_goal_state                        puzzle.py:409-411

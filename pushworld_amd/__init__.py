@@ -8,5 +8,6 @@ Drop-in for the hot path of google-deepmind/pushworld (``PushWorldPuzzle.get_nex
     from pushworld_amd.gym_env import PushWorldEnv                 # pushworld.gym_env
     from pushworld_amd.dm_env import PushWorldEnv as DmEnv         # pushworld.dm_env
     from pushworld_amd.vec_env import VecPushWorld                 # batched, new
+    from pushworld_amd.vector_env import PushWorldVectorEnv        # gymnasium.vector surface, new
 """
 __version__ = "0.1.0"

@@ -78,6 +78,11 @@ SIGNATURES = {
     "pw_engine_render_kernel": (c_int, [c_void_p, c_char_p, c_int]),
     "pw_engine_obs_stride": (c_int64, [c_void_p]),
     "pw_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "pw_mix64": (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]),
+    "pw_resample": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_uint64, c_void_p, c_int32, c_void_p],
+    ),
     "pw_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
@@ -307,6 +312,14 @@ class Engine:
     def step(self, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, flags=0):
         check(lib.pw_step(self.handle, _ptr(puzzle_id), _ptr(actions), _ptr(pos), _ptr(steps), _ptr(reward),
                           _ptr(dgoals), _ptr(terminated), _ptr(truncated), pos.shape[0], flags, self._stream()))
+
+    def resample(self, puzzle_id, episode, seed, terminated=None, truncated=None, table=None):
+        """Finished environments (flags set; both None = all) draw their next puzzle (``pw_resample``)."""
+        if table is not None and table.numel() == 0:
+            raise ValueError("pw_resample: empty sampling table")
+        check(lib.pw_resample(self.handle, _ptr(puzzle_id), _ptr(terminated), _ptr(truncated), _ptr(table),
+                              0 if table is None else table.shape[0], int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(episode),
+                              puzzle_id.shape[0], self._stream()))
 
     def rollout(self, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, reward_hist=None,
                 terminated_hist=None, truncated_hist=None, flags=0):

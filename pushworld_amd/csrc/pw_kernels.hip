@@ -242,6 +242,44 @@ __global__ __launch_bounds__(256) void pw_reset_kernel(ResetArgs a) {
 // ------------------------------------------------------------------------------------
 // K1 step  (gym_env.py:188-226 minus the observation)
 // ------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------
+// Episode management: environments whose episode has ended draw the puzzle of their
+// next episode on the device.  The reference draws with the host's Mersenne Twister
+// (gym_env.py:172 random.choice); a batch has no sequential stream to share, so the draw is a
+// counter-based hash of (seed, environment, episode number): reproducible, order independent.
+// ------------------------------------------------------------------------------------
+struct ResampleArgs {
+  int32_t* puzzle_id;
+  const uint8_t* term;
+  const uint8_t* trunc;
+  const int32_t* table;
+  uint32_t* episode;
+  uint64_t seed;
+  int32_t table_len;
+  int32_t batch;
+};
+
+// splitmix64 finaliser over the three counters (also restated in numpy by the tests)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t env, uint64_t episode) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env + 1ull) + 0xD1B54A32D192ED03ull * episode;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void pw_resample_kernel(ResampleArgs a) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= a.batch) return;
+  const bool done = (!a.term && !a.trunc) || (a.term && a.term[env]) || (a.trunc && a.trunc[env]);
+  if (!done) return;
+  const uint32_t ep = a.episode[env] + 1u;
+  a.episode[env] = ep;
+  const uint64_t r = mix64(a.seed, static_cast<uint64_t>(env), ep);
+  // floor(r * n / 2^64): unbiased to 2^-32 for n < 2^31
+  const uint32_t idx = static_cast<uint32_t>(__umul64hi(r, static_cast<uint64_t>(a.table_len)));
+  a.puzzle_id[env] = a.table ? a.table[idx] : static_cast<int32_t>(idx);
+}
+
 struct StepArgs {
   const PwPuzzleHeader* hdrs;
   const uint8_t* blob;
@@ -1417,40 +1455,51 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
   }
 
   // ---- the page holds the tail of env0 (and usually the head of env0 + 1) ------------------------
+  // Mostly bottom / top padding rows: same shape as above (4 loads in flight, LDS work only when a
+  // movable's rows reach the page).
   const int split = static_cast<int>(cpe) - c_first;  // local chunk where the next environment starts
   const bool has_second = split < 256 && env0 + 1u <= last;
-  const int pid1 = a.puzzle_id[min(env0 + 1u, last)];
+  const uint32_t env1 = min(env0 + 1u, last);
+  const int xy1 = page_load_xy(a, env1, lane);
+  const int pid1 = a.puzzle_id[env1];
   const int valid0 = static_cast<int>(ca.n_chunks) - c_first;  // local chunks [0, valid0) of env0 carry image bytes
   const uint8_t* src0 = ca.simg + static_cast<int64_t>(pid0) * ca.simg_stride + static_cast<int64_t>(c_first) * 16;
   const uint8_t* src1 = ca.simg + static_cast<int64_t>(pid1) * ca.simg_stride - static_cast<int64_t>(split) * 16;
-  if (lane < 16) pal[lane] = a.pal_rgb[lane];
-  if (lane < 8) dirty[lane] = 0;
-  for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) {
-    reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
-    reinterpret_cast<uint4*>(win1)[i] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  __syncthreads();
-  const PageEnv pe0 = page_env(a, pid0, env0, c_first * 16);
-  const PageEnv pe1 = page_env(a, pid1, env0 + 1u, -split * 16);
-  if (page_prefilter(a, pe0, lane, xy0)) page_mark(a, pe0, lane, xy0, win0, dirty);
-  if (has_second) {
-    const int xy1 = page_load_xy(a, env0 + 1u, lane);
-    if (page_prefilter(a, pe1, lane, xy1)) page_mark(a, pe1, lane, xy1, win1, dirty);
-  }
-  __syncthreads();
-#pragma unroll 1
+  u32x4 v[4];
+  bool ok[4], second[4];
+#pragma unroll
   for (int k = 0; k < 4; k++) {
     const int lc = lane + 64 * k;
-    const bool second = lc >= split;
-    const bool ok = second ? (has_second && lc - split < static_cast<int>(ca.n_chunks)) : (lc < valid0);
-    if (!ok) continue;
-    u32x4 v;
-    if ((dirty[lc >> 5] >> (lc & 31)) & 1u)
-      v = second ? page_chunk(pe1, lc - split, win1, pal) : page_chunk(pe0, c_first + lc, win0, pal);
-    else
-      v = *reinterpret_cast<const u32x4*>((second ? src1 : src0) + lc * 16);
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + k * 1024));
+    second[k] = lc >= split;
+    ok[k] = second[k] ? (has_second && lc - split < static_cast<int>(ca.n_chunks)) : (lc < valid0);
+    v[k] = u32x4{0u, 0u, 0u, 0u};
+    if (ok[k]) v[k] = *reinterpret_cast<const u32x4*>((second[k] ? src1 : src0) + lc * 16);
   }
+  const PageEnv pe0 = page_env(a, pid0, env0, c_first * 16);
+  const PageEnv pe1 = page_env(a, pid1, env0 + 1u, -split * 16);
+  const bool hit0 = page_prefilter(a, pe0, lane, xy0);
+  const bool hit1 = has_second && page_prefilter(a, pe1, lane, xy1);
+  if (hit0 || hit1) {
+    if (lane < 16) pal[lane] = a.pal_rgb[lane];
+    if (lane < 8) dirty[lane] = 0;
+    for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) {
+      reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
+      reinterpret_cast<uint4*>(win1)[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (hit0) page_mark(a, pe0, lane, xy0, win0, dirty);
+    if (hit1) page_mark(a, pe1, lane, xy1, win1, dirty);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int lc = lane + 64 * k;
+      if (ok[k] && ((dirty[lc >> 5] >> (lc & 31)) & 1u))
+        v[k] = second[k] ? page_chunk(pe1, lc - split, win1, pal) : page_chunk(pe0, c_first + lc, win0, pal);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (ok[k]) __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(dst + k * 1024));
 }
 
 // ------------------------------------------------------------------------------------
@@ -2070,6 +2119,21 @@ int pw_reset(PwEngine* e, const int32_t* puzzle_id, const uint8_t* mask, int8_t*
   const unsigned blocks = static_cast<unsigned>((threads + 255) / 256);
   hipLaunchKernelGGL(pw_reset_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("pw_reset");
+}
+
+uint64_t pw_mix64(uint64_t seed, uint64_t env, uint64_t episode) { return mix64(seed, env, episode); }
+
+int pw_resample(PwEngine* e, int32_t* puzzle_id, const uint8_t* terminated, const uint8_t* truncated,
+                const int32_t* table, int32_t table_len, uint64_t seed, uint32_t* episode, int32_t batch,
+                void* stream) {
+  if (!e || !puzzle_id || !episode) return pw_fail(PW_EINVAL, "null argument");
+  const int n = e->set->count;
+  if (table ? table_len <= 0 : (table_len != 0 && table_len != n))
+    return pw_fail(PW_EINVAL, "pw_resample: table_len must be > 0 with a table, 0 or the set size without");
+  if (batch <= 0) return PW_OK;
+  ResampleArgs a{puzzle_id, terminated, truncated, table, episode, seed, table ? table_len : n, batch};
+  hipLaunchKernelGGL(pw_resample_kernel, dim3((batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("pw_resample");
 }
 
 static int fill_step_args(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos, int32_t* steps,

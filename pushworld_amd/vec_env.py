@@ -35,13 +35,19 @@ class VecPushWorld:
         autoreset: next-step autoreset inside the step kernel.
         fused: one ``pw_step_render`` call per step (the library picks the schedule: step kernel +
             page-ordered render, or a single fused launch) instead of ``pw_step`` + ``pw_render``.
+        resample: draw a new puzzle for every new episode ON THE DEVICE (``pw_resample``), the batched
+            form of ``random.choice(self._puzzles)`` in gym_env.py:172.  ``True`` = uniform over the
+            pool; a sequence of pool indices = sampling table (repeat an index to weight it).
+            Draws happen in ``reset`` (all / masked environments) and, with ``autoreset``, at the
+            start of the ``step`` that resets a finished environment.
+        seed: seed of the counter-based draw: puzzle = f(seed, environment index, episode number).
     """
 
     def __init__(self, puzzles: Sequence[Union[str, PushWorldPuzzle]], num_envs: int,
                  puzzle_ids: Optional[Sequence[int]] = None, max_steps: Optional[int] = None,
                  border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
-                 autoreset: bool = False, fused: bool = False):
+                 autoreset: bool = False, fused: bool = False, resample=False, seed: int = 0):
         self.puzzles = [p if isinstance(p, PushWorldPuzzle) else PushWorldPuzzle(p) for p in puzzles]
         if not self.puzzles:
             raise ValueError("No PushWorld puzzles given")
@@ -75,6 +81,17 @@ class VecPushWorld:
             self._obs_storage, self.obs = None, None
         self._has_reset = False
 
+        self.seed = int(seed)
+        self.resample = resample is not False and resample is not None
+        self.sample_table = None
+        if self.resample and resample is not True:
+            tab = np.asarray(resample)
+            if tab.ndim != 1 or tab.size == 0 or tab.min() < 0 or tab.max() >= len(self.puzzles):
+                raise ValueError("resample must be True or a non-empty 1-D sequence of puzzle pool indices")
+            self.sample_table = torch.as_tensor(tab, dtype=torch.int32).to(self.device)
+        # episode number of every environment (uint32 counter bits in an int32 tensor)
+        self.episode = torch.zeros((self.num_envs,), dtype=torch.int32, device=self.device)
+
     # --------------------------------------------------------------------------------
     @property
     def num_objects_padded(self) -> int:
@@ -83,10 +100,16 @@ class VecPushWorld:
     def set_puzzle_ids(self, puzzle_ids) -> None:
         self.puzzle_id.copy_(torch.as_tensor(np.asarray(puzzle_ids), dtype=torch.int32))
 
-    def reset(self, mask: Optional[torch.Tensor] = None):
-        """gym_env.py:150-186 for every (masked) environment; returns the observation tensor."""
+    def reset(self, mask: Optional[torch.Tensor] = None, seed: Optional[int] = None):
+        """gym_env.py:150-186 for every (masked) environment; returns the observation tensor.
+        ``seed`` (with ``resample``) restarts the puzzle draw sequence: episode numbers return to 0."""
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8)
+        if seed is not None:
+            self.seed = int(seed)
+            self.episode.zero_()
+        if self.resample:
+            self.engine.resample(self.puzzle_id, self.episode, self.seed, terminated=mask, table=self.sample_table)
         self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, mask)
         self._has_reset = True
         if self.obs is not None:
@@ -106,6 +129,10 @@ class VecPushWorld:
             raise RuntimeError("reset() must be called before step() can be called.")
         if actions.dtype != torch.uint8 or actions.device != self.device or actions.shape != (self.num_envs,):
             raise ValueError("actions must be a uint8 tensor of shape [num_envs] on the engine's device")
+        if self.resample and self.flags & _capi.STEP_AUTORESET:
+            # finished environments draw the puzzle their autoreset (inside this step) starts from
+            self.engine.resample(self.puzzle_id, self.episode, self.seed, self.terminated, self.truncated,
+                                 self.sample_table)
         if self.obs is not None and self.fused:
             self.engine.step_render(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
                                     self.terminated, self.truncated, self._obs_storage, self.flags)

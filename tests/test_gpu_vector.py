@@ -1,0 +1,264 @@
+"""device-side episode management (pw_resample + autoreset) and the vector-env
+facades.  The draw is this library's own counter-based hash (the reference draws with the host
+Mersenne Twister, gym_env.py:172 -- not batchable), restated here in numpy; everything else is
+checked against the oracle environment by environment."""
+import numpy as np
+import pytest
+
+M64 = (1 << 64) - 1
+
+
+def mix64(seed, env, episode):
+    """numpy restatement of pw_mix64 (include/pushworld_amd.h, pw_resample)."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed & M64) + np.uint64(0x9E3779B97F4A7C15) * (env.astype(np.uint64) + np.uint64(1))
+             + np.uint64(0xD1B54A32D192ED03) * episode.astype(np.uint64))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def draw(seed, env, episode, n):
+    """floor(r * n / 2^64) with exact integer arithmetic."""
+    r = mix64(seed, env, episode)
+    return np.array([(int(v) * n) >> 64 for v in r], dtype=np.int64)
+
+
+def test_draw_mirror_is_uniform():
+    """CPU: the restated draw covers 0..n-1 evenly (chi-square, 68 bins, 200k draws) and does not
+    repeat across environments / episodes / seeds."""
+    n = 68
+    env = np.arange(200_000) % 4096
+    ep = np.arange(200_000) // 4096 + 1
+    idx = draw(7, env, ep, n)
+    counts = np.bincount(idx, minlength=n)
+    assert counts.min() > 0 and idx.max() == n - 1
+    chi2 = ((counts - idx.size / n) ** 2 / (idx.size / n)).sum()
+    assert chi2 < 120.0  # 67 dof: P(chi2 > 120) ~ 1e-4
+    assert (draw(7, env[:4096], ep[:4096], 1 << 20) != draw(8, env[:4096], ep[:4096], 1 << 20)).mean() > 0.99
+    assert (draw(7, env[:4096], ep[:4096], 1 << 20) != draw(7, env[:4096], ep[:4096] + 1, 1 << 20)).mean() > 0.99
+
+
+def test_mirror_equals_library_hash():
+    """CPU: the numpy restatement used by these tests equals the library's exported host copy."""
+    from pushworld_amd import _capi
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        seed, env, ep = (int(v) for v in rng.integers(0, 1 << 63, size=3))
+        env %= 1 << 31
+        ep %= 1 << 32
+        want = int(mix64(seed, np.array([env]), np.array([ep]))[0])
+        assert _capi.lib.pw_mix64(seed, env, ep) == want
+
+
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pool_keys(golden):
+    keys = [k for k in golden.keys if k.startswith("l0:")][::70][:6]
+    keys += ["pytest:trivial.pwp", "pytest:trivial_obstacle.pwp", "pytest:trivial_tool.pwp",
+             "bench:level1/2 Obstacle.pwp"]
+    return keys
+
+
+@gpu
+@pytest.mark.parametrize("use_table", [False, True])
+def test_resample_matches_mirror(golden, pool_keys, use_table):
+    """pw_resample: only finished environments draw; puzzle = f(seed, env, episode) exactly as the
+    numpy mirror; weighted table; NULL flags = everyone."""
+    import torch
+    from pushworld_amd import _capi
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    pool = [PushWorldPuzzle(text=golden.text(k)) for k in pool_keys]
+    pset = _capi.PuzzleSet([p._parsed for p in pool], 0)
+    eng = _capi.Engine(pset, None, 3, 1, _capi.OBS_U8, 0, 0)
+    dev = eng.device
+    B = 5000
+    rng = np.random.default_rng(3)
+    table_np = np.array([0, 0, 0, 3, 5, 5, 9], dtype=np.int32) if use_table else None
+    table = None if table_np is None else torch.as_tensor(table_np).to(dev)
+    n = len(table_np) if use_table else len(pool)
+    pid = torch.full((B,), 1, dtype=torch.int32, device=dev)
+    episode = torch.zeros((B,), dtype=torch.int32, device=dev)
+    want_pid = np.full(B, 1, np.int64)
+    want_ep = np.zeros(B, np.int64)
+    env = np.arange(B)
+    for it, seed in enumerate([0, 12345, (1 << 63) + 17, -5]):
+        term = (rng.random(B) < 0.3).astype(np.uint8)
+        trunc = (rng.random(B) < 0.2).astype(np.uint8) * 255
+        if it == 3:
+            eng.resample(pid, episode, seed, None, None, table)
+            done = np.ones(B, bool)
+        elif it == 2:
+            eng.resample(pid, episode, seed, torch.as_tensor(term).to(dev), None, table)
+            done = term != 0
+        else:
+            eng.resample(pid, episode, seed, torch.as_tensor(term).to(dev), torch.as_tensor(trunc).to(dev), table)
+            done = (term != 0) | (trunc != 0)
+        want_ep[done] += 1
+        idx = draw(seed, env[done], want_ep[done], n)
+        want_pid[done] = table_np[idx] if use_table else idx
+        assert (pid.cpu().numpy() == want_pid).all()
+        assert (episode.cpu().numpy() == want_ep).all()
+    with pytest.raises(ValueError):
+        eng.resample(pid, episode, 0, None, None, torch.zeros((0,), dtype=torch.int32, device=dev))
+
+
+def _simulate(golden, pool_keys, seed, B, T, max_steps, actions, table=None):
+    """Host model of the vector env: oracle per environment + the draw mirror + next-step autoreset."""
+    from oracle import pw_oracle
+
+    oz = [pw_oracle.OraclePuzzle(golden.text(k)) for k in pool_keys]
+    n = len(table) if table is not None else len(oz)
+    env = np.arange(B)
+    ep = np.ones(B, np.int64)
+    idx = draw(seed, env, ep, n)
+    pid = np.array([table[i] for i in idx]) if table is not None else idx.copy()
+    envs = [pw_oracle.OracleEnv(oz[pid[b]], max_steps) for b in range(B)]
+    for e in envs:
+        e.reset()
+    done = np.zeros(B, bool)
+    out = [dict(pid=pid.copy(), state=[e.state for e in envs])]
+    for t in range(T):
+        rew = np.zeros(B)
+        term = np.zeros(B, bool)
+        trunc = np.zeros(B, bool)
+        first = done.copy()
+        for b in range(B):
+            if done[b]:
+                ep[b] += 1
+                i = int(draw(seed, np.array([b]), np.array([ep[b]]), n)[0])
+                pid[b] = table[i] if table is not None else i
+                envs[b] = pw_oracle.OracleEnv(oz[pid[b]], max_steps)
+                envs[b].reset()
+                done[b] = False
+            else:
+                _, rew[b], term[b], trunc[b] = envs[b].step(int(actions[t, b]))
+                done[b] = term[b] or trunc[b]
+        out.append(dict(pid=pid.copy(), state=[e.state for e in envs], reward=rew, term=term, trunc=trunc,
+                        first=first, puzzles=[e.puzzle for e in envs]))
+    return oz, out
+
+
+@gpu
+@pytest.mark.parametrize("obs_kind,weighted", [("uint8", False), ("float32", True)])
+def test_vector_env_episodes_match_oracle(golden, pool_keys, obs_kind, weighted):
+    """PushWorldVectorEnv over a 10-puzzle pool, 48 environments, 120 steps with max_steps 12: puzzle ids,
+    observations (bit exact), float64 rewards, terminated / truncated equal the host model at every
+    step; episodes end by goal and by truncation and restart on freshly drawn puzzles."""
+    import torch
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vector_env import PushWorldVectorEnv
+
+    B, T, max_steps, seed = 48, 120, 12, 99
+    table = [0, 1, 1, 6, 6, 6, 7, 8, 9, 2] if weighted else None
+    rng = np.random.default_rng(5)
+    actions = rng.integers(0, 4, size=(T, B)).astype(np.uint8)
+    # bias towards RIGHT so that the trivial puzzles get solved
+    actions[rng.random((T, B)) < 0.35] = 1
+    pool = [PushWorldPuzzle(text=golden.text(k)) for k in pool_keys]
+    venv = PushWorldVectorEnv(pool, B, max_steps=max_steps, border_width=1, pixels_per_cell=3, observation=obs_kind,
+                              seed=seed, sample_table=table)
+    oz, model = _simulate(golden, pool_keys, seed, B, T, max_steps, actions, table)
+    ph, pw = max(p.height for p in oz), max(p.width for p in oz)
+    assert venv.single_observation_space.shape == (ph * 3, pw * 3, 3)
+    assert venv.observation_space.shape == (B, ph * 3, pw * 3, 3) and venv.action_space.shape == (B,)
+
+    def want_obs(puzzle, state):
+        if obs_kind == "uint8":
+            return puzzle.observation_u8(state, ph, pw, 3, 1)
+        return puzzle.observation(state, ph, pw, 3, 1)
+
+    obs, info = venv.reset(seed=seed)
+    assert (info["puzzle_id"].cpu().numpy() == model[0]["pid"]).all()
+    got = obs.cpu().numpy()
+    for b in range(B):
+        assert (got[b] == want_obs(oz[model[0]["pid"][b]], model[0]["state"][b])).all()
+    n_term = n_trunc = n_first = 0
+    for t in range(T):
+        a = torch.as_tensor(actions[t]).to(venv.vec.device)
+        if t % 2:
+            venv.step_async(a)
+            obs, reward, term, trunc, info = venv.step_wait()
+        else:
+            obs, reward, term, trunc, info = venv.step(a)
+        m = model[t + 1]
+        assert (info["puzzle_id"].cpu().numpy() == m["pid"]).all(), t
+        assert (reward.cpu().numpy().view(np.uint64) == m["reward"].view(np.uint64)).all(), t
+        assert ((term.cpu().numpy() != 0) == m["term"]).all(), t
+        assert ((trunc.cpu().numpy() != 0) == m["trunc"]).all(), t
+        got = obs.cpu().numpy()
+        for b in range(B):
+            assert (got[b] == want_obs(m["puzzles"][b], m["state"][b])).all(), (t, b)
+        n_term += int(m["term"].sum())
+        n_trunc += int(m["trunc"].sum())
+        n_first += int(m["first"].sum())
+    assert n_term > 5 and n_trunc > 50 and n_first > 50
+    # same seed -> same episode sequence again
+    obs2, info2 = venv.reset(seed=seed)
+    assert (info2["puzzle_id"].cpu().numpy() == model[0]["pid"]).all()
+    venv.close()
+
+
+@gpu
+def test_vector_env_numpy_mode_and_errors(golden, pool_keys):
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vector_env import PushWorldVectorEnv
+
+    pool = [PushWorldPuzzle(text=golden.text(k)) for k in pool_keys]
+    venv = PushWorldVectorEnv(pool, 8, max_steps=5, border_width=1, pixels_per_cell=3, to_numpy=True)
+    obs, info = venv.reset(seed=1)
+    assert isinstance(obs, np.ndarray) and obs.dtype == np.float32 and obs.shape == venv.observation_space.shape
+    assert obs.min() >= 0.0 and obs.max() <= 1.0
+    obs, reward, term, trunc, info = venv.step(np.zeros(8, np.int64))
+    assert reward.dtype == np.float64 and term.dtype == bool and trunc.dtype == bool
+    assert venv.render().dtype == np.uint8
+    for bad in (np.full(8, 4), np.zeros(7, np.int64), np.zeros(8, np.float32), np.full(8, -1)):
+        with pytest.raises(ValueError):
+            venv.step(bad)
+    venv.step_async(np.zeros(8, np.int64))
+    with pytest.raises(RuntimeError):
+        venv.step_async(np.zeros(8, np.int64))
+    venv.step_wait()
+    with pytest.raises(RuntimeError):
+        venv.step_wait()
+    with pytest.raises(ValueError):
+        PushWorldVectorEnv(pool, 8, border_width=0)
+    with pytest.raises(ValueError):
+        PushWorldVectorEnv(pool, 8, pixels_per_cell=2)
+    with pytest.raises(ValueError):
+        PushWorldVectorEnv([], 8)
+
+
+@gpu
+def test_dm_vector_env_timesteps(golden, pool_keys):
+    """Batched dm_env: FIRST after (auto)reset, LAST with discount 0 for terminated or truncated
+    (dm_env.py:229-232), MID otherwise; rewards equal the host model."""
+    import torch
+    from pushworld_amd._compat import StepType
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vector_env import PushWorldDmVectorEnv
+
+    B, T, max_steps, seed = 32, 60, 9, 4
+    rng = np.random.default_rng(8)
+    actions = rng.integers(0, 4, size=(T, B)).astype(np.uint8)
+    actions[rng.random((T, B)) < 0.35] = 1
+    pool = [PushWorldPuzzle(text=golden.text(k)) for k in pool_keys]
+    env = PushWorldDmVectorEnv(pool, B, max_steps=max_steps, border_width=1, pixels_per_cell=3, seed=seed)
+    with pytest.raises(RuntimeError):
+        env.step(torch.zeros(B, dtype=torch.uint8))
+    oz, model = _simulate(golden, pool_keys, seed, B, T, max_steps, actions)
+    ts = env.reset(seed=seed)
+    assert (ts.step_type.cpu().numpy() == int(StepType.FIRST)).all() and (ts.discount.cpu().numpy() == 1.0).all()
+    assert env.action_spec().num_values == 4 and env.observation_spec().shape == tuple(ts.observation.shape[1:])
+    for t in range(T):
+        ts = env.step(torch.as_tensor(actions[t]).to(env.vec.device))
+        m = model[t + 1]
+        done = m["term"] | m["trunc"]
+        want_type = np.where(m["first"], int(StepType.FIRST), np.where(done, int(StepType.LAST), int(StepType.MID)))
+        assert (ts.step_type.cpu().numpy() == want_type).all(), t
+        assert (ts.discount.cpu().numpy() == np.where(done, 0.0, 1.0)).all(), t
+        assert (ts.reward.cpu().numpy().view(np.uint64) == m["reward"].view(np.uint64)).all(), t
