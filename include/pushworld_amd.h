@@ -119,8 +119,14 @@ int pw_puzzleset_create(const PwPuzzle* const* puzzles, int n, int device, PwPuz
 void pw_puzzleset_destroy(PwPuzzleSet* s);
 int pw_puzzleset_size(const PwPuzzleSet* s);
 int pw_puzzleset_max_dims(const PwPuzzleSet* s, int* max_w, int* max_h, int* max_n);
-/* packed table image (host copy), for tests and on-disk caching */
+/* packed table image (host copy), for tests */
 int pw_puzzleset_blob(const PwPuzzleSet* s, const void** data, size_t* bytes);
+/* Packed puzzle-set file: the compiled pool, byte for byte what sits in HBM, behind a
+ * 64-byte header with format version and FNV-1a checksum.  Loading replaces parsing the puzzle
+ * texts again (puzzle.py:130-311 costs the reference 3 ms .. 1.5 s per puzzle).  pw_puzzleset_load
+ * validates the checksum and every table offset; PW_EPARSE for a foreign / corrupt / truncated file. */
+int pw_puzzleset_save(const PwPuzzleSet* s, const char* path);
+int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out);
 
 /* ---------------------------------------------------------------------- engine */
 int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine** out);

@@ -70,6 +70,8 @@ SIGNATURES = {
     "pw_puzzleset_size": (c_int, [c_void_p]),
     "pw_puzzleset_max_dims": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "pw_puzzleset_blob": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
+    "pw_puzzleset_save": (c_int, [c_void_p, c_char_p]),
+    "pw_puzzleset_load": (c_int, [c_char_p, c_int, POINTER(c_void_p)]),
     "pw_engine_create": (c_int, [c_void_p, POINTER(PwEngineConfig), POINTER(c_void_p)]),
     "pw_engine_destroy": (None, [c_void_p]),
     "pw_engine_npad": (c_int, [c_void_p]),
@@ -230,12 +232,33 @@ class PuzzleSet:
         check(lib.pw_puzzleset_create(arr, len(self.puzzles), device, ctypes.byref(h)))
         self.handle = h
         self.device = device
+        self.count = len(self.puzzles)
+        self._read_dims()
+
+    def _read_dims(self):
         w, hh, n = c_int(), c_int(), c_int()
-        check(lib.pw_puzzleset_max_dims(h, ctypes.byref(w), ctypes.byref(hh), ctypes.byref(n)))
+        check(lib.pw_puzzleset_max_dims(self.handle, ctypes.byref(w), ctypes.byref(hh), ctypes.byref(n)))
         self.max_width, self.max_height, self.max_movables = w.value, hh.value, n.value
 
     def __len__(self):
-        return len(self.puzzles)
+        return self.count
+
+    def save(self, path: str) -> None:
+        """Writes the packed set (``pw_puzzleset_save``)."""
+        check(lib.pw_puzzleset_save(self.handle, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path: str, device: int) -> "PuzzleSet":
+        """A set from a packed file (``pw_puzzleset_load``); ``puzzles`` is None (no parsed texts)."""
+        self = cls.__new__(cls)
+        self.puzzles = None
+        h = c_void_p()
+        check(lib.pw_puzzleset_load(os.fsencode(path), device, ctypes.byref(h)))
+        self.handle = h
+        self.device = device
+        self.count = lib.pw_puzzleset_size(h)
+        self._read_dims()
+        return self
 
     def blob(self) -> bytes:
         p, n = c_void_p(), c_size_t()

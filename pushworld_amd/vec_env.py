@@ -24,7 +24,8 @@ class VecPushWorld:
     """B environments over a pool of puzzles.
 
     Args:
-        puzzles: sequence of ``PushWorldPuzzle`` objects or ``.pwp`` paths (the pool).
+        puzzles: sequence of ``PushWorldPuzzle`` objects or ``.pwp`` paths (the pool), or a
+            ``_capi.PuzzleSet`` (e.g. ``PuzzleSet.load(path, device)`` of a packed pool file).
         num_envs: B.
         puzzle_ids: int array [B] of pool indices (default: ``i % len(puzzles)``).  Grouping
             equal ids together keeps a workgroup's puzzle tables hot in L1/L2.
@@ -48,13 +49,20 @@ class VecPushWorld:
                  border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
                  autoreset: bool = False, fused: bool = False, resample=False, seed: int = 0):
-        self.puzzles = [p if isinstance(p, PushWorldPuzzle) else PushWorldPuzzle(p) for p in puzzles]
-        if not self.puzzles:
-            raise ValueError("No PushWorld puzzles given")
         if observation not in ("uint8", "float32", None):
             raise ValueError("observation must be 'uint8', 'float32' or None")
         dev = default_device_index() if device is None else int(device)
-        self.pset = _capi.PuzzleSet([p._parsed for p in self.puzzles], dev)
+        if isinstance(puzzles, _capi.PuzzleSet):  # e.g. PuzzleSet.load(packed file): no texts, no parsing
+            if puzzles.device != dev:
+                raise ValueError(f"the puzzle set lives on device {puzzles.device}, not {dev}")
+            self.pset = puzzles
+            self.puzzles = None
+        else:
+            self.puzzles = [p if isinstance(p, PushWorldPuzzle) else PushWorldPuzzle(p) for p in puzzles]
+            if not self.puzzles:
+                raise ValueError("No PushWorld puzzles given")
+            self.pset = _capi.PuzzleSet([p._parsed for p in self.puzzles], dev)
+        self.num_puzzles = len(self.pset)
         ph, pw = pad_cells if pad_cells is not None else (0, 0)
         dtype = _capi.OBS_F32 if observation == "float32" else _capi.OBS_U8
         self.engine = _capi.Engine(self.pset, max_steps, pixels_per_cell, border_width, dtype, ph, pw)
@@ -65,10 +73,10 @@ class VecPushWorld:
         self.fused = bool(fused)
 
         if puzzle_ids is None:
-            ids = np.arange(self.num_envs) % len(self.puzzles)
+            ids = np.arange(self.num_envs) % self.num_puzzles
         else:
             ids = np.asarray(puzzle_ids)
-            if ids.shape != (self.num_envs,) or ids.min() < 0 or ids.max() >= len(self.puzzles):
+            if ids.shape != (self.num_envs,) or ids.min() < 0 or ids.max() >= self.num_puzzles:
                 raise ValueError("puzzle_ids must be [num_envs] indices into the puzzle pool")
         self.puzzle_id = torch.as_tensor(ids, dtype=torch.int32).to(self.device)
         st = self.engine.alloc_state(self.num_envs)
@@ -86,7 +94,7 @@ class VecPushWorld:
         self.sample_table = None
         if self.resample and resample is not True:
             tab = np.asarray(resample)
-            if tab.ndim != 1 or tab.size == 0 or tab.min() < 0 or tab.max() >= len(self.puzzles):
+            if tab.ndim != 1 or tab.size == 0 or tab.min() < 0 or tab.max() >= self.num_puzzles:
                 raise ValueError("resample must be True or a non-empty 1-D sequence of puzzle pool indices")
             self.sample_table = torch.as_tensor(tab, dtype=torch.int32).to(self.device)
         # episode number of every environment (uint32 counter bits in an int32 tensor)

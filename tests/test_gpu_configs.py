@@ -269,3 +269,30 @@ def test_frames_just_above_one_page(golden):
             img = o.cpu().numpy()
             for b in range(B):
                 assert (img[b] == oracles[ids[b]].observation(states[b], 18, 12, 3, 1, dtype="u8")).all(), (t, b)
+
+
+def test_engine_from_packed_set_file(golden, tmp_path):
+    """a VecPushWorld built from PuzzleSet.load(<packed file>) steps and renders exactly
+    like the one built from the puzzle texts."""
+    import torch
+    from pushworld_amd import _capi
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith(("bench:level1/", "rand:"))][::5]
+    pool = [PushWorldPuzzle(text=golden.text(k)) for k in keys]
+    B, T = 512, 40
+    a = VecPushWorld(pool, B, max_steps=25, pixels_per_cell=3, border_width=1, observation="uint8", autoreset=True)
+    path = str(tmp_path / "pool.pwset")
+    a.pset.save(path)
+    b = VecPushWorld(_capi.PuzzleSet.load(path, a.device.index), B, max_steps=25, pixels_per_cell=3, border_width=1,
+                     observation="uint8", autoreset=True)
+    assert b.puzzles is None and b.num_puzzles == len(pool) and b.engine.obs_shape == a.engine.obs_shape
+    acts = torch.randint(0, 4, (T, B), dtype=torch.uint8, device=a.device, generator=torch.Generator(device=a.device).manual_seed(3))
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    for t in range(T):
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), t
+    assert torch.equal(a.pos, b.pos)

@@ -188,3 +188,51 @@ def test_puzzleset_host_packing(golden):
     assert s.max_width == max(p.width for p in ps) and s.max_movables == max(p.num_movables for p in ps)
     with pytest.raises(RuntimeError, match="no device tables"):
         _capi.Engine(s, None, 3, 1, _capi.OBS_U8)
+
+
+def test_packed_set_file_round_trip_and_rejects_corruption(golden, tmp_path):
+    """pw_puzzleset_save / pw_puzzleset_load (host-only sets, no GPU): the loaded set is
+    byte-identical; foreign, truncated, bit-flipped and offset-corrupted files are refused."""
+    keys = [k for k in golden.keys if k.startswith(("bench:level1/", "pytest:", "rand:"))][::3]
+    parsed = [_capi.ParsedPuzzle(golden.text(k)) for k in keys]
+    pset = _capi.PuzzleSet(parsed, -1)
+    path = str(tmp_path / "pool.pwset")
+    pset.save(path)
+    back = _capi.PuzzleSet.load(path, -1)
+    assert len(back) == len(pset) == len(keys)
+    assert (back.max_width, back.max_height, back.max_movables) == (pset.max_width, pset.max_height, pset.max_movables)
+    assert back.blob() == pset.blob()
+    raw = open(path, "rb").read()
+    assert raw[:5] == b"PWSET" and len(raw) == 64 + 320 * len(keys) + len(pset.blob())
+
+    def refused(data):
+        bad = str(tmp_path / "bad.pwset")
+        with open(bad, "wb") as f:
+            f.write(data)
+        with pytest.raises(ValueError):
+            _capi.PuzzleSet.load(bad, -1)
+
+    refused(b"")
+    refused(b"not a puzzle set" * 10)
+    refused(raw[:-16])                                   # truncated
+    flipped = bytearray(raw)
+    flipped[64 + 320 * len(keys) + 5] ^= 0x40            # payload bit flip -> checksum
+    refused(bytes(flipped))
+    wrong_version = bytearray(raw)
+    wrong_version[8] = 9
+    refused(bytes(wrong_version))
+    with pytest.raises(ValueError):
+        _capi.PuzzleSet.load(str(tmp_path / "missing.pwset"), -1)
+    # a well-formed file (valid checksum) whose first table offset points outside the blob
+    evil = bytearray(raw)
+    evil[64:68] = struct.pack("<I", 0xFFFFFFF0)         # PwPuzzleHeader.base of puzzle 0
+    h = 0xCBF29CE484222325
+    for byte in evil[64:]:
+        h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    evil[40:48] = struct.pack("<Q", h)
+    refused(bytes(evil))
+    evil[64:68] = raw[64:68]                             # restoring the offset (+ its checksum) loads again
+    h = 0xCBF29CE484222325
+    for byte in evil[64:]:
+        h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    assert struct.pack("<Q", h) == raw[40:48]
