@@ -208,6 +208,33 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
 int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ,
                uint32_t* moved, uint8_t* goal, int32_t num_states, void* stream);
 
+/* ---------------------------------------------------------- planner frontier services
+ * Breadth-first exploration of ONE puzzle with the closed set on the device.  The reference
+ * planner pops one node, calls getNextState x4 and looks each successor up in a
+ * std::unordered_set<State> (best_first_search.h:72-93); here every call expands a whole layer:
+ * pw_expand4 semantics for the successors, an open-addressing visited table in HBM, and the new
+ * states appended to a store with (parent, action) links.  State numbering is deterministic and
+ * equals the one of a sequential FIFO search trying the actions in the order 0..3 (state 0 = start).
+ * All device memory is allocated by pw_search_create (about max_states * (2N + 21) bytes + scratch). */
+typedef struct PwSearch PwSearch;
+int pw_search_create(PwEngine* e, int32_t puzzle, int64_t max_states, PwSearch** out);
+void pw_search_destroy(PwSearch* s);
+/* start: host int32 [N] Position2D (x * 10000 + y), NULL = the puzzle's initial state */
+int pw_search_begin(PwSearch* s, const int32_t* start, void* stream);
+/* Expands the newest layer and synchronises the stream.
+ *   info[0] depth of the new layer   info[1] states in it (0 = search space exhausted)
+ *   info[2] states in the store      info[3] lowest index of a goal state found so far, or -1
+ * PW_ELIMIT when the store is full (the new layer is then incomplete). */
+int pw_search_expand(PwSearch* s, int64_t info[4], void* stream);
+/* dst: device int32 [count][N] Position2D of states first .. first + count - 1 */
+int pw_search_read_states(PwSearch* s, int64_t first, int64_t count, int32_t* dst, void* stream);
+/* device int32 [count] parent indices (-1 for the start) and uint8 [count] actions; either may be NULL */
+int pw_search_read_links(PwSearch* s, int64_t first, int64_t count, int32_t* parent, uint8_t* action,
+                         void* stream);
+/* actions (host buffer) from the start to state `index`; returns the plan length (if > cap nothing
+ * is written: call again with a larger buffer) or a negative error. */
+int pw_search_plan(PwSearch* s, int64_t index, uint8_t* actions, int32_t cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

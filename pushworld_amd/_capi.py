@@ -101,6 +101,13 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          c_int64, c_int32, c_uint32, c_void_p],
     ),
+    "pw_search_create": (c_int, [c_void_p, c_int32, c_int64, POINTER(c_void_p)]),
+    "pw_search_destroy": (None, [c_void_p]),
+    "pw_search_begin": (c_int, [c_void_p, POINTER(c_int32), c_void_p]),
+    "pw_search_expand": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
+    "pw_search_read_states": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "pw_search_read_links": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "pw_search_plan": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "pw_expand4": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
 }
 

@@ -2326,3 +2326,5 @@ int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ
 }
 
 }  // extern "C"
+
+#include "pw_search.inc"

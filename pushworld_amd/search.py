@@ -1,0 +1,133 @@
+"""Breadth-first search with the frontier and the closed set on the GPU.
+
+The reference planner (cpp/include/search/best_first_search.h:72-93) pops one node at a time and
+calls ``getNextState`` four times; ``BreadthFirstSearch`` expands a whole layer per call through the
+``pw_search_*`` entry points.  State numbering is deterministic: it is the numbering of a sequential
+FIFO search that tries the actions in the order LEFT, RIGHT, UP, DOWN, so plans are the first
+shortest plan in that order.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from .puzzle import PushWorldPuzzle
+
+POSITION_LIMIT = 10000  # pushworld_puzzle.h:37
+
+
+class LayerInfo(tuple):
+    """(depth, new_states, total_states, goal_index) of one ``expand`` call."""
+
+    depth = property(lambda self: self[0])
+    new_states = property(lambda self: self[1])
+    total_states = property(lambda self: self[2])
+    goal_index = property(lambda self: self[3])
+
+
+class BreadthFirstSearch:
+    """Layer-synchronous BFS over the states of one puzzle.
+
+    Args:
+        puzzle: a ``PushWorldPuzzle`` (object order as parsed: Python order by default).
+        max_states: capacity of the state store (device memory ~ ``max_states * (2 N + 21)`` bytes).
+    """
+
+    def __init__(self, puzzle: PushWorldPuzzle, max_states: int = 1 << 22):
+        self.puzzle = puzzle
+        self._engine = puzzle._engine()
+        self.device = self._engine.device
+        self.num_objects = puzzle.num_movables
+        self.max_states = int(max_states)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib.pw_search_create(self._engine.handle, 0, self.max_states, ctypes.byref(h)))
+        self.handle = h
+        self.total_states = 0
+        self.layers: List[Tuple[int, int]] = []  # (first index, count) per depth
+        self.goal_index = -1
+        self.exhausted = False
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def begin(self, start: Optional[Sequence[Tuple[int, int]]] = None) -> None:
+        """Starts a search from ``start`` (a reference-style state, default: the initial state)."""
+        arr = None
+        if start is not None:
+            if len(start) != self.num_objects:
+                raise ValueError("start must hold one (x, y) pair per movable")
+            arr = (ctypes.c_int32 * self.num_objects)(*[int(x) * POSITION_LIMIT + int(y) for x, y in start])
+        _capi.check(_capi.lib.pw_search_begin(self.handle, arr, self._stream()))
+        self.total_states = 1
+        self.layers = [(0, 1)]
+        state0 = tuple(start) if start is not None else self.puzzle.initial_state
+        self.goal_index = 0 if self.puzzle.is_goal_state(state0) else -1
+        self.exhausted = False
+
+    def expand(self) -> LayerInfo:
+        """Expands the newest layer; raises ``ValueError`` when the store is full."""
+        info = (ctypes.c_int64 * 4)()
+        rc = _capi.lib.pw_search_expand(self.handle, info, self._stream())
+        depth, new, total, goal = (int(v) for v in info)
+        if rc == _capi.PW_ELIMIT and total > self.total_states:  # store full: the last layer is incomplete
+            self.layers.append((total - new, new))
+            self.total_states = total
+            self.goal_index = goal
+        _capi.check(rc)
+        if new:
+            self.layers.append((total - new, new))
+        else:
+            self.exhausted = True
+        self.total_states = total
+        self.goal_index = goal
+        return LayerInfo((depth, new, total, goal))
+
+    def states(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """int array [count, N, 2] of (x, y) positions of states ``first .. first + count - 1``."""
+        count = self.total_states - first if count is None else count
+        out = torch.empty((count, self.num_objects), dtype=torch.int32, device=self.device)
+        _capi.check(_capi.lib.pw_search_read_states(self.handle, first, count, _capi._ptr(out), self._stream()))
+        v = out.cpu().numpy()
+        return np.stack([v // POSITION_LIMIT, v % POSITION_LIMIT], axis=-1)
+
+    def links(self, first: int = 0, count: Optional[int] = None):
+        """(parent int32 [count], action uint8 [count]); the start state has parent -1."""
+        count = self.total_states - first if count is None else count
+        par = torch.empty((count,), dtype=torch.int32, device=self.device)
+        act = torch.empty((count,), dtype=torch.uint8, device=self.device)
+        _capi.check(_capi.lib.pw_search_read_links(self.handle, first, count, _capi._ptr(par), _capi._ptr(act),
+                                                   self._stream()))
+        return par.cpu().numpy(), act.cpu().numpy()
+
+    def plan(self, index: int) -> List[int]:
+        """Actions leading from the start state to state ``index``."""
+        cap = 256
+        while True:
+            buf = (ctypes.c_uint8 * cap)()
+            n = _capi.check(_capi.lib.pw_search_plan(self.handle, int(index), buf, cap, self._stream()))
+            if n <= cap:
+                return [int(buf[i]) for i in range(n)]
+            cap = n
+
+    def solve(self, max_depth: Optional[int] = None) -> Optional[List[int]]:
+        """A shortest plan (first in L, R, U, D order), or None if the reachable space holds no goal
+        state within ``max_depth``.  ``ValueError`` if ``max_states`` is exhausted first."""
+        if not self.layers:
+            self.begin()
+        while self.goal_index < 0 and not self.exhausted:
+            if max_depth is not None and len(self.layers) - 1 >= max_depth:
+                return None
+            self.expand()
+        return self.plan(self.goal_index) if self.goal_index >= 0 else None
+
+    def close(self) -> None:
+        h = getattr(self, "handle", None)
+        if h and _capi.lib is not None:
+            _capi.lib.pw_search_destroy(h)
+            self.handle = None
+
+    __del__ = close

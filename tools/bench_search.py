@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""GPU breadth-first search throughput (pw_search_*): explores benchmark puzzles layer by layer until the goal,
+exhaustion or --max-states, and reports parents expanded per second (each parent = 4 successors + closed-set
+lookups + insertion) next to a host FIFO search over the oracle's C port on a bounded prefix.
+
+    python tools/bench_search.py [--max-states N]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import deque
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def host_rate(text, seconds=3.0):
+    from oracle import c_oracle
+
+    oz = c_oracle.COraclePuzzle(text, order="cpp")
+    s0 = oz.initial_state
+    seen = {s0}
+    q = deque([s0])
+    t0 = time.perf_counter()
+    n = 0
+    while q and time.perf_counter() - t0 < seconds:
+        s = q.popleft()
+        n += 1
+        for a in range(4):
+            t = oz.get_next_state(s, a)
+            if t != s and t not in seen:
+                seen.add(t)
+                q.append(t)
+    return n / (time.perf_counter() - t0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-states", type=int, default=40_000_000)
+    args = ap.parse_args()
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.search import BreadthFirstSearch
+
+    d = os.path.join(ROOT, "pushworld_amd", "data", "puzzles")
+    out = {}
+    for rel in ("level1/2 Obstacle.pwp", "level1/Choose Wisely.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp"):
+        with open(os.path.join(d, rel)) as f:
+            text = f.read()
+        pz = PushWorldPuzzle(text=text, order="cpp")
+        bfs = BreadthFirstSearch(pz, max_states=args.max_states)
+        bfs.begin()
+        bfs.expand()  # warm-up launch
+        bfs.begin()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        status = "exhausted"
+        try:
+            while not bfs.exhausted:
+                info = bfs.expand()
+                if info.goal_index >= 0:
+                    status = "solved"
+                    break
+        except ValueError:
+            status = "store full"
+        dt = time.perf_counter() - t0
+        # parents whose successors were generated: everything before the newest layer
+        expanded = bfs.total_states if status == "exhausted" else bfs.layers[-1][0]
+        ent = {"status": status, "movables": pz.num_movables, "depth": len(bfs.layers) - 1, "states": bfs.total_states,
+               "parents_expanded": expanded, "seconds": dt, "parents_per_s": expanded / dt,
+               "largest_layer": max(c for _, c in bfs.layers)}
+        if status == "solved":
+            plan = bfs.plan(bfs.goal_index)
+            ent["plan_length"] = len(plan)
+            ent["plan_valid"] = bool(pz.is_valid_plan(plan))
+        ent["host_fifo_parents_per_s"] = host_rate(text)
+        out[rel] = ent
+        bfs.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
