@@ -96,7 +96,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the RCCL path even with one rank (smoke test of the N > 1 plumbing on a 1-GPU box)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist  # RCCL over xGMI; used only for the timing barrier/reduction
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
