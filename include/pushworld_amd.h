@@ -216,8 +216,26 @@ int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ
  * states appended to a store with (parent, action) links.  State numbering is deterministic and
  * equals the one of a sequential FIFO search trying the actions in the order 0..3 (state 0 = start).
  * All device memory is allocated by pw_search_create (about max_states * (2N + 21) bytes + scratch). */
+/* Novelty tables: NoveltyHeuristic::estimate_cost_to_goal (cpp/src/heuristics/novelty.cc:30-77) for a
+ * whole array of states.  novelty[k] is what the reference returns for state k when the states are fed
+ * to it one after the other in index order, this call after all earlier calls: 1 = a moved object is at
+ * a position it never had, 2 = a (moved object, other object) pair of positions is new, 3 = neither.
+ *   states  device int32 [count][state_size] Position2D, inside the width x height grid
+ *   moved   device uint32 [count], bit i = object i is in moved_object_indices (pw_expand4's `moved`)
+ * Memory: state_size * (state_size - 1) / 2 * (width * height)^2 * 4 bytes for the pair table. */
+typedef struct PwNovelty PwNovelty;
+int pw_novelty_create(int device, int state_size, int width, int height, PwNovelty** out);
+void pw_novelty_destroy(PwNovelty* n);
+int pw_novelty_reset(PwNovelty* n, void* stream);
+int pw_novelty_eval(PwNovelty* n, const int32_t* states, const uint32_t* moved, uint8_t* novelty,
+                    int32_t count, void* stream);
+
 typedef struct PwSearch PwSearch;
-int pw_search_create(PwEngine* e, int32_t puzzle, int64_t max_states, PwSearch** out);
+/* novelty_width 0: breadth-first search.  1 or 2: width-limited search IW(k) (Lipovetzky & Geffner) on
+ * the reference's novelty definition: every new state gets its novelty (tables updated in discovery
+ * order, the start state with all objects moved, best_first_search.h:58-67); states whose novelty exceeds
+ * the width stay in the closed set but are not expanded. */
+int pw_search_create(PwEngine* e, int32_t puzzle, int64_t max_states, int32_t novelty_width, PwSearch** out);
 void pw_search_destroy(PwSearch* s);
 /* start: host int32 [N] Position2D (x * 10000 + y), NULL = the puzzle's initial state */
 int pw_search_begin(PwSearch* s, const int32_t* start, void* stream);
@@ -231,6 +249,8 @@ int pw_search_read_states(PwSearch* s, int64_t first, int64_t count, int32_t* ds
 /* device int32 [count] parent indices (-1 for the start) and uint8 [count] actions; either may be NULL */
 int pw_search_read_links(PwSearch* s, int64_t first, int64_t count, int32_t* parent, uint8_t* action,
                          void* stream);
+/* device uint8 [count]: 1 = state was cut by the novelty width (never expanded), 0 otherwise */
+int pw_search_read_flags(PwSearch* s, int64_t first, int64_t count, uint8_t* pruned, void* stream);
 /* actions (host buffer) from the start to state `index`; returns the plan length (if > cap nothing
  * is written: call again with a larger buffer) or a negative error. */
 int pw_search_plan(PwSearch* s, int64_t index, uint8_t* actions, int32_t cap, void* stream);

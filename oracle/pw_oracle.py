@@ -351,6 +351,37 @@ class OracleEnv:
         return self.state, reward, terminated, truncated
 
 
+class OracleNovelty:
+    """Restatement of ``NoveltyHeuristic`` (cpp/src/heuristics/novelty.cc:20-77, Lipovetzky & Geffner's
+    width-based novelty capped at 3): 1 if a moved object sits at a position it never had in any state
+    given before, 2 if a (moved object, other object) pair of positions is new, 3 otherwise.  Every atom of
+    the moved objects is recorded whatever the result.  Positions are any hashable values."""
+
+    def __init__(self, state_size):
+        self.state_size = state_size
+        self.positions = [set() for _ in range(state_size)]
+        self.pairs = {}
+
+    def estimate(self, state, moved_object_indices):
+        novelty = 3
+        for i in moved_object_indices:
+            p_i = state[i]
+            if p_i not in self.positions[i]:  # novelty.cc:43-45
+                self.positions[i].add(p_i)
+                novelty = 1
+            for j in range(self.state_size):
+                if j == i:
+                    continue
+                lo, hi = (j, i) if j < i else (i, j)  # smaller index first, novelty.cc:50-72
+                atom = (state[lo], state[hi])
+                seen = self.pairs.setdefault((lo, hi), set())
+                if atom not in seen:
+                    seen.add(atom)
+                    if novelty > 2:
+                        novelty = 2
+        return novelty
+
+
 def position2d(x, y):
     """pushworld_puzzle.h:32-37 / cc:176-178: ``x * 10000 + y``."""
     return x * 10000 + y

@@ -101,7 +101,12 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          c_int64, c_int32, c_uint32, c_void_p],
     ),
-    "pw_search_create": (c_int, [c_void_p, c_int32, c_int64, POINTER(c_void_p)]),
+    "pw_novelty_create": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "pw_novelty_destroy": (None, [c_void_p]),
+    "pw_novelty_reset": (c_int, [c_void_p, c_void_p]),
+    "pw_novelty_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "pw_search_create": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(c_void_p)]),
+    "pw_search_read_flags": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "pw_search_destroy": (None, [c_void_p]),
     "pw_search_begin": (c_int, [c_void_p, POINTER(c_int32), c_void_p]),
     "pw_search_expand": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),

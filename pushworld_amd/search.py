@@ -35,16 +35,21 @@ class BreadthFirstSearch:
     Args:
         puzzle: a ``PushWorldPuzzle`` (object order as parsed: Python order by default).
         max_states: capacity of the state store (device memory ~ ``max_states * (2 N + 21)`` bytes).
+        novelty_width: 0 = breadth-first search; 1 or 2 = width-limited search IW(k): new states whose
+            novelty (reference ``NoveltyHeuristic``, novelty.cc:30-77) exceeds the width are closed but
+            never expanded.  Incomplete but usually far smaller; plans are no longer guaranteed shortest.
     """
 
-    def __init__(self, puzzle: PushWorldPuzzle, max_states: int = 1 << 22):
+    def __init__(self, puzzle: PushWorldPuzzle, max_states: int = 1 << 22, novelty_width: int = 0):
         self.puzzle = puzzle
         self._engine = puzzle._engine()
         self.device = self._engine.device
         self.num_objects = puzzle.num_movables
         self.max_states = int(max_states)
         h = ctypes.c_void_p()
-        _capi.check(_capi.lib.pw_search_create(self._engine.handle, 0, self.max_states, ctypes.byref(h)))
+        self.novelty_width = int(novelty_width)
+        _capi.check(_capi.lib.pw_search_create(self._engine.handle, 0, self.max_states, self.novelty_width,
+                                               ctypes.byref(h)))
         self.handle = h
         self.total_states = 0
         self.layers: List[Tuple[int, int]] = []  # (first index, count) per depth
@@ -103,6 +108,13 @@ class BreadthFirstSearch:
                                                    self._stream()))
         return par.cpu().numpy(), act.cpu().numpy()
 
+    def pruned(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """bool [count]: states cut by the novelty width (closed, never expanded)."""
+        count = self.total_states - first if count is None else count
+        out = torch.empty((count,), dtype=torch.uint8, device=self.device)
+        _capi.check(_capi.lib.pw_search_read_flags(self.handle, first, count, _capi._ptr(out), self._stream()))
+        return out.cpu().numpy().astype(bool)
+
     def plan(self, index: int) -> List[int]:
         """Actions leading from the start state to state ``index``."""
         cap = 256
@@ -128,6 +140,49 @@ class BreadthFirstSearch:
         h = getattr(self, "handle", None)
         if h and _capi.lib is not None:
             _capi.lib.pw_search_destroy(h)
+            self.handle = None
+
+    __del__ = close
+
+
+class NoveltyTables:
+    """Batched ``NoveltyHeuristic`` (cpp/src/heuristics/novelty.cc:30-77): ``evaluate`` returns, for an
+    array of states, the values the reference would return when fed the states one by one in order."""
+
+    def __init__(self, state_size: int, width: int, height: int, device: Optional[int] = None):
+        from .puzzle import default_device_index
+
+        self.device_index = default_device_index() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.state_size = int(state_size)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib.pw_novelty_create(self.device_index, self.state_size, int(width), int(height),
+                                                ctypes.byref(h)))
+        self.handle = h
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self) -> None:
+        _capi.check(_capi.lib.pw_novelty_reset(self.handle, self._stream()))
+
+    def evaluate(self, states: torch.Tensor, moved: torch.Tensor) -> torch.Tensor:
+        """``states`` int32 [F, N] Position2D (x * 10000 + y), ``moved`` int32/uint32-bit masks [F];
+        returns uint8 [F] novelties (1, 2 or 3)."""
+        if states.dtype != torch.int32 or states.dim() != 2 or states.shape[1] != self.state_size or \
+                not states.is_contiguous() or states.device != self.device:
+            raise ValueError("states must be a contiguous int32 tensor [F, state_size] on the tables' device")
+        if moved.shape != (states.shape[0],) or moved.dtype not in (torch.int32, torch.uint32) or moved.device != self.device:
+            raise ValueError("moved must be an int32 tensor [F] of bit masks on the tables' device")
+        out = torch.empty((states.shape[0],), dtype=torch.uint8, device=self.device)
+        _capi.check(_capi.lib.pw_novelty_eval(self.handle, _capi._ptr(states), _capi._ptr(moved), _capi._ptr(out),
+                                              states.shape[0], self._stream()))
+        return out
+
+    def close(self) -> None:
+        h = getattr(self, "handle", None)
+        if h and _capi.lib is not None:
+            _capi.lib.pw_novelty_destroy(h)
             self.handle = None
 
     __del__ = close

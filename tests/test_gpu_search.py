@@ -178,3 +178,142 @@ def test_bfs_large_layer_matches_host_prefix(golden):
     par, act = bfs.links(0, n)
     assert (par == np.array(want_parent[:n])).all() and (act[1:] == np.array(want_action[1:n])).all()
     bfs.close()
+
+
+# ------------------------------------------------------------------------------------------- novelty
+def test_novelty_tables_reference_known_answers():
+    """cpp/test/heuristics/test_novelty_heuristic.cc:86-106: the reference's own sequence, evaluated in
+    one batch and again split over several calls (the tables persist between calls)."""
+    import torch
+    from pushworld_amd.search import NoveltyTables
+
+    states = [[1, 2, 3, 4], [2, 3, 4, 5], [1, 3, 4, 5], [2, 3, 3, 5], [1, 3, 3, 5], [1, 3, 3, 4], [1, 3, 5, 4], [1, 3, 5, 4]]
+    moved = [0b1111, 0b1111, 0b0001, 0b0100, 0b0101, 0b1000, 0b0100, 0]
+    want = [1, 1, 2, 2, 3, 2, 1, 3]
+    nt = NoveltyTables(4, 1, 6)
+    st = torch.tensor(states, dtype=torch.int32, device=nt.device)
+    mv = torch.tensor(moved, dtype=torch.int32, device=nt.device)
+    assert nt.evaluate(st, mv).cpu().tolist() == want
+    nt.reset()
+    got = []
+    for lo, hi in ((0, 1), (1, 4), (4, 8)):
+        got += nt.evaluate(st[lo:hi].contiguous(), mv[lo:hi].contiguous()).cpu().tolist()
+    assert got == want
+    with pytest.raises(ValueError):  # y = 6 is outside the 1 x 6 grid
+        nt.evaluate(torch.tensor([[1, 2, 6, 4]], dtype=torch.int32, device=nt.device), mv[:1].contiguous())
+    with pytest.raises(ValueError):
+        nt.evaluate(st[:, :3].contiguous(), mv)
+    nt.close()
+
+
+@pytest.mark.parametrize("n,w,h", [(5, 6, 5), (1, 3, 3), (12, 9, 7), (32, 4, 3)])
+def test_novelty_tables_equal_sequential_oracle(n, w, h):
+    """Random states and moved masks: the batched tables return exactly what the restated
+    NoveltyHeuristic returns when fed the same states one at a time."""
+    import torch
+    from oracle import pw_oracle
+    from pushworld_amd.search import NoveltyTables
+
+    rng = np.random.default_rng(n * 100 + w)
+    F = 6000
+    xs, ys = rng.integers(0, w, (F, n)), rng.integers(0, h, (F, n))
+    masks = rng.integers(0, 1 << min(n, 31), F).astype(np.int64)
+    masks[rng.random(F) < 0.5] &= rng.integers(0, 1 << min(n, 31), F)[rng.random(F) < 0.5].sum() | 1  # sparser masks
+    masks[::17] = 0
+    if n == 32:
+        masks[::5] |= 1 << 31
+    oracle = pw_oracle.OracleNovelty(n)
+    want = [oracle.estimate(tuple(zip(xs[k], ys[k])), [i for i in range(n) if (int(masks[k]) >> i) & 1]) for k in range(F)]
+    nt = NoveltyTables(n, w, h)
+    st = torch.as_tensor((xs * 10000 + ys).astype(np.int32)).to(nt.device)
+    mv = torch.as_tensor(masks.astype(np.uint32).view(np.int32)).to(nt.device)
+    got = []
+    for lo, hi in ((0, 1), (1, 1000), (1000, 1003), (1003, F)):
+        got += nt.evaluate(st[lo:hi].contiguous(), mv[lo:hi].contiguous()).cpu().tolist()
+    assert got == want
+    assert set(want) == ({1, 2, 3} if n > 1 else {1, 3})
+    nt.close()
+
+
+def host_iw(oz, width, max_states=None):
+    """FIFO search with novelty pruning, the host model of pw_search_create(novelty_width = width)."""
+    from oracle import pw_oracle
+
+    s0 = oz.initial_state
+    is_goal = oz.py.is_goal_state
+    n = len(s0)
+    nov = pw_oracle.OracleNovelty(n)
+    nov.estimate(s0, range(n))
+    states, parent, action, depth, pruned = [s0], [-1], [255], [0], [False]
+    index = {s0: 0}
+    goal = 0 if is_goal(s0) else -1
+    q = deque([0])
+    while q:
+        i = q.popleft()
+        for a in range(4):
+            nxt, moved = oz.get_next_state_moved(states[i], a)
+            if not moved or nxt in index:
+                continue
+            k = len(states)
+            index[nxt] = k
+            states.append(nxt)
+            parent.append(i)
+            action.append(a)
+            depth.append(depth[i] + 1)
+            if goal < 0 and is_goal(nxt):
+                goal = k
+            cut = nov.estimate(nxt, moved) > width
+            pruned.append(cut)
+            if not cut:
+                q.append(k)
+            if max_states is not None and len(states) >= max_states:
+                return states, parent, action, depth, pruned, goal
+    return states, parent, action, depth, pruned, goal
+
+
+@pytest.mark.parametrize("width", [1, 2])
+@pytest.mark.parametrize("chunk", [None, "5"])
+def test_width_limited_search_equals_host_model(golden, width, chunk, monkeypatch):
+    """IW(1) / IW(2): states, links, pruned flags, layers and first goal equal the host model built from
+    the oracle step and the restated NoveltyHeuristic; with 5-parent passes as well."""
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.search import BreadthFirstSearch
+
+    if chunk:
+        monkeypatch.setenv("PUSHWORLD_AMD_SEARCH_CHUNK", chunk)
+    else:
+        monkeypatch.delenv("PUSHWORLD_AMD_SEARCH_CHUNK", raising=False)
+    keys = CASES + ["bench:level1/2 Obstacle.pwp", "bench:level1/Choose Wisely.pwp", "bench:level2/Pull Dont Push.pwp",
+                    "cpptest:file_parsing.pwp"]
+    n_checked = n_pruned = n_solved = 0
+    for key in keys:
+        if key not in golden.meta:
+            continue
+        text = golden.text(key)
+        oz = c_oracle.COraclePuzzle(text)
+        cap = 1500 if chunk else 30000
+        states, parent, action, depth, pruned, goal = host_iw(oz, width, max_states=cap + 1)
+        if len(states) > cap:
+            continue
+        pz = PushWorldPuzzle(text=text)
+        bfs = BreadthFirstSearch(pz, max_states=cap + 8, novelty_width=width)
+        bfs.begin()
+        while not bfs.exhausted:
+            bfs.expand()
+        assert bfs.total_states == len(states), key
+        got = bfs.states()
+        assert (got == np.array(states, dtype=np.int64).reshape(got.shape)).all(), key
+        par, act = bfs.links()
+        assert (par == np.array(parent)).all() and (act[1:] == np.array(action[1:])).all(), key
+        assert (bfs.pruned() == np.array(pruned)).all(), key
+        assert [c for _, c in bfs.layers] == np.bincount(np.array(depth)).tolist(), key
+        assert bfs.goal_index == goal, key
+        if goal >= 0:
+            plan = bfs.plan(goal)
+            assert len(plan) == depth[goal] and pz.is_valid_plan(plan)
+            n_solved += 1
+        n_pruned += int(np.sum(pruned))
+        n_checked += 1
+        bfs.close()
+    assert n_checked >= 6 and n_pruned > 0 and n_solved >= 3

@@ -190,3 +190,14 @@ def test_python_and_cpp_orders_agree_up_to_permutation(golden):
             sb = b_.get_next_state(sb, int(act))
             assert tuple(sb[p] for p in perm) == sa, k
             assert a_.is_goal_state(sa) == b_.is_goal_state(sb)
+
+
+def test_novelty_oracle_known_answers():
+    """cpp/test/heuristics/test_novelty_heuristic.cc:86-106 transcribed as data: the sequence of
+    (state, moved indices) -> novelty the reference asserts for NoveltyHeuristic(4)."""
+    nov = pw_oracle.OracleNovelty(4)
+    seq = [((1, 2, 3, 4), (0, 1, 2, 3), 1), ((2, 3, 4, 5), (0, 1, 2, 3), 1), ((1, 3, 4, 5), (0,), 2),
+           ((2, 3, 3, 5), (2,), 2), ((1, 3, 3, 5), (0, 2), 3), ((1, 3, 3, 4), (3,), 2), ((1, 3, 5, 4), (2,), 1),
+           ((1, 3, 5, 4), (), 3)]
+    for state, moved, want in seq:
+        assert nov.estimate(state, moved) == want, (state, moved)
