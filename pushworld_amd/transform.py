@@ -1,0 +1,67 @@
+"""The 8 dihedral variants of a puzzle (same surface as python3/src/pushworld/transform.py).
+
+Used to widen a training pool: the variants are ordinary puzzles, so they go through the normal
+host compiler into the packed set (8 x the tables, still a few MB per thousand puzzles).  Names and
+output formatting follow the reference: ``r{0,90,180,270}`` = clockwise rotation, ``_flipped`` =
+top-bottom flip applied BEFORE the rotation; tokens joined by two spaces, rows by a newline.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Sequence
+
+from .config import PUZZLE_EXTENSION
+
+TRANSFORM_NAMES = tuple(f"r{rot}{suffix}" for suffix in ("", "_flipped") for rot in (0, 90, 180, 270))
+
+# action ids: 0 LEFT, 1 RIGHT, 2 UP, 3 DOWN (puzzle.py:43-56)
+_ROT90 = {2: 1, 1: 3, 3: 0, 0: 2}   # one clockwise quarter turn: UP -> RIGHT -> DOWN -> LEFT -> UP
+_FLIP = {2: 3, 3: 2, 0: 0, 1: 1}    # top-bottom flip
+
+
+def _rotate_clockwise(grid: List[List[str]]) -> List[List[str]]:
+    rows, cols = len(grid), len(grid[0])
+    return [[grid[rows - 1 - c][r] for c in range(rows)] for r in range(cols)]
+
+
+def get_puzzle_transforms(puzzle_string: str) -> Dict[str, str]:
+    """All 8 combinations of quarter turns and a flip of a ``.pwp`` puzzle text (transform.py:21-48)."""
+    base = [line.split() for line in puzzle_string.splitlines()]
+    out = {}
+    for suffix, grid in (("", base), ("_flipped", base[::-1])):
+        for rot in (0, 90, 180, 270):
+            out[f"r{rot}{suffix}"] = "\n".join("  ".join(row) for row in grid)
+            grid = _rotate_clockwise(grid)
+    return out
+
+
+def transform_plan(plan: Sequence[int], transform_name: str) -> List[int]:
+    """The plan that does in the transformed puzzle what ``plan`` does in the original
+    (the mapping python3/test/test_transform.py:47-79 checks)."""
+    if transform_name not in TRANSFORM_NAMES:
+        raise ValueError(f"unknown transform {transform_name!r}")
+    actions = [int(a) for a in plan]
+    if transform_name.endswith("_flipped"):
+        actions = [_FLIP[a] for a in actions]
+    for _ in range(int(transform_name[1:].split("_")[0]) // 90):
+        actions = [_ROT90[a] for a in actions]
+    return actions
+
+
+def create_transformed_puzzles(puzzle_path: str, output_path: str) -> None:
+    """Writes the 8 variants of every puzzle under ``puzzle_path`` to ``output_path`` as
+    ``<relative name>_<transform>.pwp`` (transform.py:51-85)."""
+    root = puzzle_path.rstrip(os.path.sep)
+    for subdir, _, filenames in os.walk(root):
+        for filename in filenames:
+            if not filename.endswith(PUZZLE_EXTENSION):
+                continue
+            src = os.path.join(subdir, filename)
+            with open(src, "r") as f:
+                variants = get_puzzle_transforms(f.read())
+            prefix = os.path.splitext(src[len(root) + 1:])[0]
+            for name, text in variants.items():
+                dst = os.path.join(output_path, f"{prefix}_{name}{PUZZLE_EXTENSION}")
+                os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+                with open(dst, "w") as f:
+                    f.write(text)
