@@ -235,6 +235,28 @@ def main():
                 "rest_of_step_ms": 1000.0 * elapsed / K - float(ms.mean()),  # step kernel + launch gaps
             }
             out["config"]["algorithmic_bytes_per_env_step"] = eng.obs_bytes + state_bytes
+        # extra (not the headline): the same loop with the observation buffer maintained incrementally
+        # (pw_step_render_delta: same bytes in HBM after every step, only the changed pixel rows written)
+        if obs_mode == "uint8" and args.ppc == 3 and args.bw == 1:
+            try:
+                def delta_step(t):
+                    eng.step_render_delta(vec.puzzle_id, actions[t], vec.pos, vec.steps, vec.reward, vec.dgoals,
+                                          vec.terminated, vec.truncated, vec._obs_storage, vec.flags)
+                for t in range(Wm):
+                    delta_step(t)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for t in range(K):
+                    delta_step(Wm + t)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                out["incremental_render"] = {
+                    "env_steps_per_s": B * K / dt, "ms_per_step": 1000.0 * dt / K, "n_gpus": 1,
+                    "note": "pw_step_render_delta on this rank: observation buffer bit-identical to the full render "
+                            "after every step (tests/test_gpu_incremental.py); not the headline value",
+                }
+            except Exception as exc:  # noqa: BLE001
+                out["incremental_render"] = {"error": repr(exc)}
         # extra (not the headline): the same batch state-only, T steps per launch (pw_rollout)
         try:
             Tn = 64

@@ -198,6 +198,18 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
                    uint8_t* truncated, void* obs, int64_t env_stride_bytes, int32_t batch,
                    uint32_t flags, void* stream);
 
+/* Incremental form of pw_step_render for observation buffers that persist between steps.
+ * PRECONDITION: on entry `obs` holds the observation of the state in `pos` (as left by pw_render,
+ * pw_step_render or a previous pw_step_render_delta on the same buffers).  On return every output,
+ * including every byte of `obs`, equals what pw_step_render produces -- but only the pixel rows swept
+ * by the objects that moved are written (none for a blocked move; the whole image for environments
+ * reset by PW_STEP_AUTORESET, which also covers a puzzle_id changed by pw_resample).  uint8 /
+ * pixels_per_cell 3 engines; any other engine silently takes the pw_step_render path. */
+int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
+                         int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
+                         uint8_t* truncated, void* obs, int64_t env_stride_bytes, int32_t batch,
+                         uint32_t flags, void* stream);
+
 /* Planner successor expansion, best_first_search.h:76-78 calling
  * PushWorldPuzzle::getNextState (pushworld_puzzle.cc:386-460) and satisfiesGoal (:462-469)
  * for all 4 actions of F states of ONE puzzle (index `puzzle`, normally PW_ORDER_CPP).

@@ -113,6 +113,11 @@ SIGNATURES = {
     "pw_search_read_states": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "pw_search_read_links": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "pw_search_plan": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
+    "pw_step_render_delta": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_int64, c_int32, c_uint32, c_void_p],
+    ),
     "pw_expand4": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
 }
 
@@ -372,6 +377,13 @@ class Engine:
         check(lib.pw_step_render(self.handle, _ptr(puzzle_id), _ptr(actions), _ptr(pos), _ptr(steps),
                                  _ptr(reward), _ptr(dgoals), _ptr(terminated), _ptr(truncated),
                                  _ptr(obs_storage), self.obs_stride, pos.shape[0], flags, self._stream()))
+
+    def step_render_delta(self, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, obs_storage,
+                          flags=0):
+        """``pw_step_render_delta``: ``obs_storage`` must hold the observation of ``pos`` on entry."""
+        check(lib.pw_step_render_delta(self.handle, _ptr(puzzle_id), _ptr(actions), _ptr(pos), _ptr(steps),
+                                       _ptr(reward), _ptr(dgoals), _ptr(terminated), _ptr(truncated),
+                                       _ptr(obs_storage), self.obs_stride, pos.shape[0], flags, self._stream()))
 
     def expand4(self, puzzle_index, states, succ, moved, goal):
         check(lib.pw_expand4(self.handle, int(puzzle_index), _ptr(states), _ptr(succ), _ptr(moved), _ptr(goal),

@@ -36,6 +36,10 @@ class VecPushWorld:
         autoreset: next-step autoreset inside the step kernel.
         fused: one ``pw_step_render`` call per step (the library picks the schedule: step kernel +
             page-ordered render, or a single fused launch) instead of ``pw_step`` + ``pw_render``.
+        incremental: keep the observation buffer up to date with ``pw_step_render_delta``: a step
+            rewrites only the pixel rows swept by the objects that moved (the buffer persists between
+            steps, so everything else is already right).  Same observations, a fraction of the HBM
+            writes; uint8 / pixels_per_cell 3 only (other settings fall back to the full render).
         resample: draw a new puzzle for every new episode ON THE DEVICE (``pw_resample``), the batched
             form of ``random.choice(self._puzzles)`` in gym_env.py:172.  ``True`` = uniform over the
             pool; a sequence of pool indices = sampling table (repeat an index to weight it).
@@ -48,7 +52,8 @@ class VecPushWorld:
                  puzzle_ids: Optional[Sequence[int]] = None, max_steps: Optional[int] = None,
                  border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
-                 autoreset: bool = False, fused: bool = False, resample=False, seed: int = 0):
+                 autoreset: bool = False, fused: bool = False, resample=False, seed: int = 0,
+                 incremental: bool = False):
         if observation not in ("uint8", "float32", None):
             raise ValueError("observation must be 'uint8', 'float32' or None")
         dev = default_device_index() if device is None else int(device)
@@ -71,6 +76,8 @@ class VecPushWorld:
         self.observation = observation
         self.flags = _capi.STEP_AUTORESET if autoreset else 0
         self.fused = bool(fused)
+        self.incremental = bool(incremental)
+        self._obs_current = False  # the observation buffer holds the observation of self.pos
 
         if puzzle_ids is None:
             ids = np.arange(self.num_envs) % self.num_puzzles
@@ -106,6 +113,7 @@ class VecPushWorld:
         return self.engine.np
 
     def set_puzzle_ids(self, puzzle_ids) -> None:
+        self._obs_current = False
         self.puzzle_id.copy_(torch.as_tensor(np.asarray(puzzle_ids), dtype=torch.int32))
 
     def reset(self, mask: Optional[torch.Tensor] = None, seed: Optional[int] = None):
@@ -122,6 +130,7 @@ class VecPushWorld:
         self._has_reset = True
         if self.obs is not None:
             self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+            self._obs_current = True
         return self.obs
 
     def step(self, actions: torch.Tensor):
@@ -141,7 +150,10 @@ class VecPushWorld:
             # finished environments draw the puzzle their autoreset (inside this step) starts from
             self.engine.resample(self.puzzle_id, self.episode, self.seed, self.terminated, self.truncated,
                                  self.sample_table)
-        if self.obs is not None and self.fused:
+        if self.obs is not None and self.incremental and self._obs_current:
+            self.engine.step_render_delta(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
+                                          self.terminated, self.truncated, self._obs_storage, self.flags)
+        elif self.obs is not None and self.fused:
             self.engine.step_render(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
                                     self.terminated, self.truncated, self._obs_storage, self.flags)
         else:
@@ -149,6 +161,7 @@ class VecPushWorld:
                              self.terminated, self.truncated, self.flags)
             if self.obs is not None:
                 self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+        self._obs_current = self.obs is not None
         return self.obs, self.reward, self.terminated, self.truncated
 
     def rollout(self, actions: torch.Tensor, history: bool = False):
@@ -169,6 +182,7 @@ class VecPushWorld:
             rh = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
             th = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
             uh = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+        self._obs_current = False
         self.engine.rollout(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals, self.terminated,
                             self.truncated, rh, th, uh, self.flags)
         if history:
@@ -180,6 +194,7 @@ class VecPushWorld:
         if self.obs is None:
             raise RuntimeError("this VecPushWorld was created with observation=None")
         self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+        self._obs_current = True
         return self.obs
 
     def states(self) -> np.ndarray:
@@ -189,3 +204,4 @@ class VecPushWorld:
     def set_states(self, pos: np.ndarray) -> None:
         self.pos.copy_(torch.as_tensor(np.asarray(pos), dtype=torch.int8))
         self._has_reset = True
+        self._obs_current = False

@@ -81,7 +81,7 @@ def _load_pool(puzzle_path, standard_padding: bool):
 class _VectorCore:
     def __init__(self, puzzle_path, num_envs: int, max_steps: Optional[int], border_width: int, pixels_per_cell: int,
                  standard_padding: bool, observation: str, seed: int, sample_table, device: Optional[int],
-                 to_numpy: bool):
+                 to_numpy: bool, incremental: bool = True):
         if border_width < 1:
             raise ValueError("border_width must be >= 1")
         if pixels_per_cell < 3:
@@ -92,7 +92,7 @@ class _VectorCore:
         self.vec = VecPushWorld(puzzles, num_envs, max_steps=max_steps, border_width=border_width,
                                 pixels_per_cell=pixels_per_cell, observation=observation, pad_cells=pad,
                                 device=device, autoreset=True, resample=True if sample_table is None else sample_table,
-                                seed=seed)
+                                seed=seed, incremental=incremental)
         self.num_envs = int(num_envs)
         self.to_numpy = bool(to_numpy)
         self._obs_dtype = np.float32 if observation == "float32" else np.uint8

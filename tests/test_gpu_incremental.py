@@ -1,0 +1,94 @@
+"""pw_step_render_delta (incremental observation maintenance) against the full render: every byte of
+the observation buffer, every step, under autoreset, puzzle re-sampling, illegal overlapping
+states, several frames.  The full render itself is pinned to the reference in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pool(golden, keys):
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    return [PushWorldPuzzle(text=golden.text(k)) for k in keys]
+
+
+@pytest.mark.parametrize("pad,resample", [(None, False), ((54, 47), False), (None, True)])
+def test_incremental_equals_full_render_level1(golden, pad, resample):
+    import torch
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith("bench:level1/")]
+    pool = _pool(golden, keys)
+    B, T = 1536, 130
+    ids = (np.arange(B) * len(pool)) // B
+    kw = dict(puzzle_ids=ids, max_steps=35, pixels_per_cell=3, border_width=1, observation="uint8", pad_cells=pad,
+              autoreset=True, resample=resample, seed=11)
+    full = VecPushWorld(pool, B, **kw)
+    inc = VecPushWorld(pool, B, incremental=True, **kw)
+    assert inc.engine.render_kernel in ("pw_render_page_kernel", "pw_render_u8_ppc3_kernel")
+    g = torch.Generator(device=full.device).manual_seed(2)
+    acts = torch.randint(0, 4, (T, B), dtype=torch.uint8, device=full.device, generator=g)
+    assert torch.equal(full.reset(seed=11), inc.reset(seed=11))
+    n_reset = 0
+    for t in range(T):
+        done_before = (full.terminated | full.truncated) != 0
+        n_reset += int(done_before.sum())
+        fo = full.step(acts[t])
+        io = inc.step(acts[t])
+        for x, y in zip(fo, io):
+            assert torch.equal(x, y), t
+        assert torch.equal(full.pos, inc.pos) and torch.equal(full.puzzle_id, inc.puzzle_id), t
+        assert torch.equal(full._obs_storage, inc._obs_storage), t  # including the stride padding bytes
+    assert n_reset > B  # every env went through at least one autoreset on average
+
+
+def test_incremental_handles_overlapping_states_and_small_frames(golden):
+    """Random in-bounds states where objects overlap each other, walls and goals (the states of the
+    'not already overlapping' parity tests): first step renders fully, the following ones incrementally."""
+    import torch
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith(("pytest:", "rand:"))][:60]
+    pool = _pool(golden, keys)
+    B = len(pool) * 8
+    ids = np.arange(B) % len(pool)
+    rng = np.random.default_rng(5)
+    full = VecPushWorld(pool, B, puzzle_ids=ids, pixels_per_cell=3, border_width=1, observation="uint8")
+    inc = VecPushWorld(pool, B, puzzle_ids=ids, pixels_per_cell=3, border_width=1, observation="uint8", incremental=True)
+    full.reset()
+    inc.reset()
+    pos = np.zeros((B, full.engine.np, 2), np.int8)
+    for b in range(B):
+        p = pool[ids[b]]
+        w, h = p.dimensions
+        for j in range(p.num_movables):
+            pos[b, j] = (rng.integers(1, max(2, w - 1)), rng.integers(1, max(2, h - 1)))
+    full.set_states(pos)
+    inc.set_states(pos)
+    g = torch.Generator(device=full.device).manual_seed(9)
+    for t in range(40):
+        a = torch.randint(0, 4, (B,), dtype=torch.uint8, device=full.device, generator=g)
+        fo, io = full.step(a), inc.step(a)
+        assert torch.equal(fo[0], io[0]), t
+        assert torch.equal(full.pos, inc.pos), t
+        if t == 20:  # an external state change invalidates the buffer: next step falls back to the full path
+            inc.set_states(full.states())
+            full.set_states(full.states())
+
+
+def test_incremental_falls_back_for_other_settings(golden):
+    """float32 / other pixel sizes have no incremental kernel: same results through the full path."""
+    import torch
+    from pushworld_amd.vec_env import VecPushWorld
+
+    pool = _pool(golden, ["pytest:trivial_tool.pwp", "bench:level1/2 Obstacle.pwp"])
+    for kw in (dict(observation="float32", pixels_per_cell=3, border_width=1), dict(observation="uint8", pixels_per_cell=8, border_width=2)):
+        full = VecPushWorld(pool, 64, max_steps=9, autoreset=True, **kw)
+        inc = VecPushWorld(pool, 64, max_steps=9, autoreset=True, incremental=True, **kw)
+        full.reset()
+        inc.reset()
+        g = torch.Generator(device=full.device).manual_seed(1)
+        for t in range(25):
+            a = torch.randint(0, 4, (64,), dtype=torch.uint8, device=full.device, generator=g)
+            assert torch.equal(full.step(a)[0], inc.step(a)[0]), t
