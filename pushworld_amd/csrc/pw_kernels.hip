@@ -45,14 +45,9 @@ struct PwEngine {
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
   int step_kernel;         // 0 group (default), 1 wavefront per env, 2 lane per env (PUSHWORLD_AMD_STEP)
   bool force_fused;        // PUSHWORLD_AMD_FUSED=1: pw_step_render always uses the single fused launch
-  bool two_pass_render;    // PUSHWORLD_AMD_RENDER=copy: copy kernel + patch kernel instead of the page kernel
-  bool overlay_render;     // PUSHWORLD_AMD_RENDER=overlay: mark kernel + page-ordered overlay kernel
   uint16_t* d_dirty;       // per-environment dirty row interval of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
-  uint8_t* d_overlay;      // per-environment overlay records (grown on demand)
-  int64_t overlay_cap;     // environments the buffer holds
-  int32_t max_mcells;      // largest movable-cell count in the puzzle set
-  uint8_t* d_simg;         // per puzzle: observation of the static layers only (copy+patch render path)
+  uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)
   int64_t simg_stride;     // bytes between the static images of consecutive puzzles
   uint16_t* d_estat;       // per puzzle: static zone-colour table in this engine's frame layout
   uint32_t* d_estat_off;   // byte offset of puzzle p's table in d_estat (16 B aligned)
@@ -1112,16 +1107,7 @@ __global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_u8_ppc3_kernel(Re
   }
 }
 
-// ------------------------------------------------------------------------------------
-// Copy + patch render path (uint8, ppc 3): the observation of a state differs from the
-// observation of the puzzle's static layers only under the movables (1.2 % of the bytes on the
-// Level-1 mix), and HBM takes ~25 % more write bandwidth when the whole chip sweeps 4 KiB
-// pages in address order (profiles/r01_store_pattern.txt).  So:
-//   pass 1  pw_render_copy_kernel   short-lived workgroups, one 4 KiB page of the obs buffer each,
-//                                   in address order: L2-resident static image -> HBM
-//   pass 2  pw_render_patch_kernel  one wavefront per environment draws the 9-byte pixel triples
-//                                   of the cells under the movables over it
-// ------------------------------------------------------------------------------------
+// geometry of the page-ordered kernels below: the observation buffer as a flat run of 16-byte chunks
 struct CopyArgs {
   const uint8_t* simg;
   const int32_t* puzzle_id;
@@ -1132,159 +1118,6 @@ struct CopyArgs {
   uint32_t n_chunks;        // 16-byte chunks of one observation
   float inv_cpe;            // 1 / chunks_per_env
 };
-
-#ifndef PW_COPY_THREADS
-#define PW_COPY_THREADS 64  // workgroup = one 4 KiB page = one wavefront; each lane moves 4 chunks
-#endif
-__global__ __launch_bounds__(PW_COPY_THREADS) void pw_render_copy_kernel(CopyArgs a) {
-  constexpr int kPerThread = 256 / PW_COPY_THREADS;
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  // The page holds chunks [g0, g0 + 256) of at most two environments: their puzzle ids are
-  // workgroup-uniform (scalar loads), so a lane's only dependent access is the image load.
-  const uint32_t g0 = blockIdx.x * 256u;
-  const uint32_t env0 = g0 / a.chunks_per_env;
-  const uint32_t last = static_cast<uint32_t>(a.batch) - 1u;
-  const int pid0 = a.puzzle_id[min(env0, last)];
-  const int pid1 = a.puzzle_id[min(env0 + 1u, last)];
-  const uint32_t split = (env0 + 1u) * a.chunks_per_env;  // first chunk of the next environment
-  u32x4 v[kPerThread];
-  bool ok[kPerThread];
-#pragma unroll
-  for (int k = 0; k < kPerThread; k++) {
-    const uint32_t g = g0 + threadIdx.x + k * PW_COPY_THREADS;
-    const bool second = g >= split;
-    const uint32_t env = second ? env0 + 1u : env0;
-    const uint32_t c = g - env * a.chunks_per_env;
-    ok[k] = env <= last && c < a.n_chunks;
-    const int pid = second ? pid1 : pid0;
-    const uint8_t* src = a.simg + static_cast<int64_t>(pid) * a.simg_stride + static_cast<int64_t>(c) * 16;
-    if (ok[k]) v[k] = *reinterpret_cast<const u32x4*>(src);
-  }
-#pragma unroll
-  for (int k = 0; k < kPerThread; k++) {
-    const uint32_t g = g0 + threadIdx.x + k * PW_COPY_THREADS;
-    uint8_t* dst = a.obs + static_cast<int64_t>(g) * 16;
-    // streaming (nt) store: the 3.8 GB output stream should not displace the static images the
-    // loads are served from
-#if defined(PW_COPY_PLAIN_STORE)
-    if (ok[k]) *reinterpret_cast<u32x4*>(dst) = v[k];
-#elif defined(PW_COPY_SC1_STORE)
-    if (ok[k]) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v[k]) : "memory");
-#else
-    if (ok[k]) __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(dst));  // measured best (profiles/)
-#endif
-  }
-}
-
-__device__ __forceinline__ void draw_cell_ppc3(const uint32_t* pal, int W, int H, int G, int pad_w, const uint16_t* estat,
-                                               uint8_t* out, uint32_t c, int p, int c0, int shift_bytes) {
-  const int obj = c >> 24;
-  const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
-  const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
-  if (static_cast<unsigned>(x) >= static_cast<unsigned>(W) || static_cast<unsigned>(y) >= static_cast<unsigned>(H)) return;
-  const uint32_t kind = obj == 0 ? 3u : (obj <= G ? 4u : 5u);
-  const uint32_t om = (c >> 16) & 0xffu;
-  const int q0 = 3 * y * pad_w + x + c0;
-  uint32_t se[3];
-#pragma unroll
-  for (int zy = 0; zy < 3; zy++) se[zy] = estat[q0 + zy * pad_w];
-#pragma unroll
-  for (int zy = 0; zy < 3; zy++) {
-    const uint32_t e = pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_entry_goal_bits(se[zy]));
-    const uint32_t r0 = pal[e & 15u], r1 = pal[(e >> 4) & 15u], r2 = pal[(e >> 8) & 15u];
-    uint8_t* d = out + (9 * (q0 + zy * pad_w) + shift_bytes);
-    const uint32_t w0 = r0 | (r1 << 24), w1 = (r1 >> 8) | (r2 << 16), w2 = r2 >> 16;  // 9 bytes
-    if (reinterpret_cast<uintptr_t>(d) & 1) {
-      d[0] = static_cast<uint8_t>(w0);
-      *reinterpret_cast<uint16_t*>(d + 1) = static_cast<uint16_t>(w0 >> 8);
-      *reinterpret_cast<uint16_t*>(d + 3) = static_cast<uint16_t>((w0 >> 24) | (w1 << 8));
-      *reinterpret_cast<uint16_t*>(d + 5) = static_cast<uint16_t>(w1 >> 8);
-      *reinterpret_cast<uint16_t*>(d + 7) = static_cast<uint16_t>((w1 >> 24) | (w2 << 8));
-    } else {
-      *reinterpret_cast<uint16_t*>(d) = static_cast<uint16_t>(w0);
-      *reinterpret_cast<uint16_t*>(d + 2) = static_cast<uint16_t>(w0 >> 16);
-      *reinterpret_cast<uint16_t*>(d + 4) = static_cast<uint16_t>(w1);
-      *reinterpret_cast<uint16_t*>(d + 6) = static_cast<uint16_t>(w1 >> 16);
-      d[8] = static_cast<uint8_t>(w2);
-    }
-  }
-}
-
-// GS lanes per environment (GS = 16 when the padded object count is <= 16, else 32): lane l of a
-// group holds object l's position and bounding box, and draws cell m0 + l of the movable-cell list.
-template <int GS>
-__global__ __launch_bounds__(256) void pw_render_patch_kernel(RenderArgs a) {
-  __shared__ uint32_t pal[16];
-  if (threadIdx.x < 16) pal[threadIdx.x] = a.pal_rgb[threadIdx.x];
-  __syncthreads();
-  constexpr int kGroups = 256 / GS;
-  const int lane = threadIdx.x & (PW_WAVE - 1);
-  const int lj = threadIdx.x & (GS - 1);          // lane within the group
-  const int gbase = lane & ~(GS - 1);             // first lane of the group inside the wave
-  const int env = blockIdx.x * kGroups + static_cast<int>(threadIdx.x) / GS;
-  const bool live = env < a.batch;
-  const int pid = live ? a.puzzle_id[env] : 0;
-  const PwPuzzleHeader* h = a.hdrs + pid;
-  const int W = h->W, H = h->H, N = live ? h->N : 0, G = h->G;
-  const int n_mcells = live ? static_cast<int>(h->n_mcells) : 0;
-  const uint32_t* mcells = reinterpret_cast<const uint32_t*>(a.blob + h->base + h->off_mcells);
-
-  int xy = 0;
-  uint32_t ot = 0;
-  if (live && lj < N) {
-    xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + lj]);
-    ot = reinterpret_cast<const uint32_t*>(h->objtab)[lj];
-  }
-  // Conservative overlap test: do the bounding boxes of two movables intersect?  If none do, no
-  // two movables share a cell and all cells can be drawn at once; otherwise the objects are drawn
-  // one after the other so that a higher index wins (puzzle.py:457).
-  const int bx0 = static_cast<int8_t>(xy & 0xff), by0 = static_cast<int8_t>((xy >> 8) & 0xff);
-  const int bx1 = bx0 + static_cast<int>(ot & 0xffu), by1 = by0 + static_cast<int>((ot >> 8) & 0xffu);
-  const int nmax = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, N));
-  bool touch = false;
-  for (int k = 1; k < nmax; k++) {
-    const int partner = (lj + k < N) ? lj + k : lj + k - N;  // (lj + k) mod N for k < N
-    const int src = gbase + (k < N ? partner : lj);
-    const int oxy = __shfl(xy, src, PW_WAVE);
-    const uint32_t oot = static_cast<uint32_t>(__shfl(static_cast<int>(ot), src, PW_WAVE));
-    const int ox0 = static_cast<int8_t>(oxy & 0xff), oy0 = static_cast<int8_t>((oxy >> 8) & 0xff);
-    const int ox1 = ox0 + static_cast<int>(oot & 0xffu), oy1 = oy0 + static_cast<int>((oot >> 8) & 0xffu);
-    if (lj < N && k < N && bx0 < ox1 && ox0 < bx1 && by0 < oy1 && oy0 < by1) touch = true;
-  }
-  const unsigned long long tmask = __ballot(touch);
-  const bool ordered = ((tmask >> gbase) & ((1ull << GS) - 1ull)) != 0ull;
-
-  const int wpx = a.pad_w * 3;
-  const int pady = (a.pad_h - H) * 3 / 2;
-  const int padx = (a.pad_w - W) * 3 / 2;
-  const int c0 = (padx + 2) / 3;
-  const int shift_bytes = 3 * (pady * wpx + padx - 3 * c0);
-  const uint16_t* estat = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[pid]);
-  uint8_t* out = a.obs + static_cast<int64_t>(env) * a.env_stride;
-
-  const int cmax = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, n_mcells));
-  const bool any_ordered = __ballot(ordered) != 0ull;
-  // pass over the cell list; groups that need painter order only draw the agent here
-  for (int m0 = 0; m0 < cmax; m0 += GS) {
-    const int m = m0 + lj;
-    const uint32_t c = m < n_mcells ? mcells[m] : 0u;
-    const int p = __shfl(xy, gbase + static_cast<int>(c >> 24), PW_WAVE);
-    if (m < n_mcells && (!ordered || (c >> 24) == 0u))
-      draw_cell_ppc3(pal, W, H, G, a.pad_w, estat, out, c, p, c0, shift_bytes);
-  }
-  if (any_ordered) {
-    for (int j = 1; j < nmax; j++) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // object j - 1 is in L2 before object j is drawn
-      for (int m0 = 0; m0 < cmax; m0 += GS) {
-        const int m = m0 + lj;
-        const uint32_t c = m < n_mcells ? mcells[m] : 0u;
-        const int p = __shfl(xy, gbase + static_cast<int>(c >> 24), PW_WAVE);
-        if (ordered && m < n_mcells && static_cast<int>(c >> 24) == j)
-          draw_cell_ppc3(pal, W, H, G, a.pad_w, estat, out, c, p, c0, shift_bytes);
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------
 // Page render (uint8, ppc 3): ONE pass, page ordered.  A workgroup is a single wavefront that
@@ -1589,259 +1422,6 @@ __global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyA
   }
 }
 
-// ------------------------------------------------------------------------------------
-// Overlay render (uint8, ppc 3; PUSHWORLD_AMD_RENDER=overlay): page-ordered output with the
-// per-environment work hoisted out of the page workgroups.
-//   pw_render_mark_kernel   one wavefront per environment: which 16-byte chunks of its image
-//                           differ from the puzzle's static image (a bitmap + running counts),
-//                           and their final bytes, in a compact per-environment record
-//   pw_render_ovl_kernel    one wavefront per 4 KiB page of the observation buffer, in address
-//                           order: every chunk is ONE 16-byte load (static image or record) and
-//                           ONE 16-byte store; no LDS, no barrier
-// ------------------------------------------------------------------------------------
-#define PW_OV_HASH 1024  // open-addressing table of the patched entries of one environment
-#define PW_OV_EMPTY 0xFFFFFFFFu
-
-struct OverlayArgs {
-  uint8_t* overlay;    // [batch] records: uint32 bits[w32] | uint16 prefix[w32] | uint8 bytes[max_dirty][16]
-  int64_t rec_bytes;
-  int32_t w32;         // bitmap words = chunks_per_env / 32
-  int32_t off_prefix, off_bytes;
-  int32_t max_dirty;
-};
-
-__global__ __launch_bounds__(64) void pw_render_mark_kernel(RenderArgs a, OverlayArgs ov) {
-  extern __shared__ __align__(16) uint32_t mark_lds[];
-  __shared__ uint32_t pal[16];
-  const int lane = threadIdx.x;
-  const int w32 = ov.w32;
-  uint32_t* bits = mark_lds;
-  uint32_t* prefix = bits + w32;
-  uint32_t* htab = bits + ((2 * w32 + 3) & ~3);  // packed q << 17 | object << 12 | entry, or PW_OV_EMPTY
-  if (lane < 16) pal[lane] = a.pal_rgb[lane];
-  const int env = blockIdx.x;
-  const bool live = true;
-
-  // phase 0: clear the tables
-  for (int i = lane; i < 2 * w32; i += PW_WAVE) bits[i] = 0u;
-  for (int i = lane; i < PW_OV_HASH / 4; i += PW_WAVE)
-    reinterpret_cast<uint4*>(htab)[i] = make_uint4(PW_OV_EMPTY, PW_OV_EMPTY, PW_OV_EMPTY, PW_OV_EMPTY);
-  __syncthreads();
-
-  const int pid = __builtin_amdgcn_readfirstlane(a.puzzle_id[env]);
-  const PwPuzzleHeader* h = a.hdrs + pid;
-  const int W = h->W, H = h->H, N = h->N, G = h->G, n_mcells = static_cast<int>(h->n_mcells);
-  const uint32_t* mcells = reinterpret_cast<const uint32_t*>(a.blob + h->base + h->off_mcells);
-  const uint16_t* estat = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[pid]);
-  const int pady = (a.pad_h - H) * 3 / 2;
-  const int padx = (a.pad_w - W) * 3 / 2;
-  const int c0 = (padx + 2) / 3;
-  const int shift_bytes = 3 * (pady * a.pad_w * 3 + padx - 3 * c0);
-  const int n_entries = 3 * H * a.pad_w;
-
-  // phase 1: zone entries of the movable cells -> hash table (highest object index wins a shared
-  // entry = painter order, puzzle.py:457); chunks they reach into -> bitmap
-  int xy = 0;
-  if (lane < N) xy = static_cast<uint16_t>(reinterpret_cast<const int16_t*>(a.pos)[static_cast<int64_t>(env) * a.np + lane]);
-  for (int m0 = 0; m0 < n_mcells; m0 += PW_WAVE) {
-    const int m = m0 + lane;
-    const uint32_t c = m < n_mcells ? mcells[m] : 0u;
-    const int obj = c >> 24;
-    const int p = __shfl(xy, obj, PW_WAVE);
-    const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
-    const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
-    if (m >= n_mcells || static_cast<unsigned>(x) >= static_cast<unsigned>(W) || static_cast<unsigned>(y) >= static_cast<unsigned>(H))
-      continue;
-    const uint32_t kind = obj == 0 ? 3u : (obj <= G ? 4u : 5u);
-    const uint32_t om = (c >> 16) & 0xffu;
-    const int qtop = 3 * y * a.pad_w + x + c0;
-    uint32_t se[3];
-#pragma unroll
-    for (int zy = 0; zy < 3; zy++) se[zy] = estat[qtop + zy * a.pad_w];
-#pragma unroll
-    for (int zy = 0; zy < 3; zy++) {
-      const int q = qtop + zy * a.pad_w;
-      const uint32_t e = pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_entry_goal_bits(se[zy]));
-      const uint32_t mine = (static_cast<uint32_t>(q) << 17) | (static_cast<uint32_t>(obj) << 12) | e;
-      uint32_t slot = (static_cast<uint32_t>(q) * 2654435761u) >> 22;  // 10 bits
-      for (;;) {
-        const uint32_t cur = htab[slot];
-        if (cur == PW_OV_EMPTY || (cur >> 17) == static_cast<uint32_t>(q)) {
-          const uint32_t want = (cur == PW_OV_EMPTY || mine > cur) ? mine : cur;
-          if (want == cur || atomicCAS(&htab[slot], cur, want) == cur) break;
-        } else {
-          slot = (slot + 1u) & (PW_OV_HASH - 1);
-        }
-      }
-      const int b0 = 9 * q + shift_bytes;
-      const int cl = b0 >> 4, ch = (b0 + 8) >> 4;
-      atomicOr(&bits[cl >> 5], 1u << (cl & 31));
-      atomicOr(&bits[ch >> 5], 1u << (ch & 31));
-    }
-  }
-  __syncthreads();
-
-  // phase 2: prefix[w] = number of dirty chunks in words < w (contiguous word ranges per lane)
-  const int per = (w32 + PW_WAVE - 1) / PW_WAVE;
-  int mine = 0;
-  for (int k = 0; k < per; k++) {
-    const int w = lane * per + k;
-    if (w < w32) mine += __popc(bits[w]);
-  }
-  int incl = mine;
-#pragma unroll
-  for (int d = 1; d < PW_WAVE; d <<= 1) {
-    const int up = __shfl_up(incl, d, PW_WAVE);
-    if (lane >= d) incl += up;
-  }
-  const int total = __shfl(incl, PW_WAVE - 1, PW_WAVE);
-  int run = incl - mine;
-  for (int k = 0; k < per; k++) {
-    const int w = lane * per + k;
-    if (w < w32) {
-      prefix[w] = static_cast<uint32_t>(run);
-      run += __popc(bits[w]);
-    }
-  }
-  __syncthreads();
-
-  // phase 3: final bytes of the dirty chunks, chunk of rank r by lane r % 64
-  uint8_t* rec = ov.overlay + static_cast<int64_t>(env) * ov.rec_bytes;
-  const int bias_q = (shift_bytes > 0 ? shift_bytes / 9 : 0) + 2;
-  const int n_dirty = min(total, ov.max_dirty);
-  for (int r = lane; r < n_dirty; r += PW_WAVE) {
-    // last word w with prefix[w] <= r
-    int lo = 0, hi = w32 - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (static_cast<int>(prefix[mid]) <= r) lo = mid;
-      else hi = mid - 1;
-    }
-    uint32_t v = bits[lo];
-    for (int i = r - static_cast<int>(prefix[lo]); i > 0; i--) v &= v - 1u;
-    const int c = lo * 32 + (__ffs(v) - 1);
-    const unsigned o3 = static_cast<unsigned>(c * 16 - shift_bytes + 9 * bias_q);
-    const unsigned qb = o3 / 9u;
-    const int b = static_cast<int>(o3 - qb * 9u);
-    const int q0 = static_cast<int>(qb) - bias_q;
-    uint32_t ee[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const int q = q0 + t;
-      uint32_t e = (static_cast<unsigned>(q) < static_cast<unsigned>(n_entries)) ? estat[q] : 0u;
-      if (q >= 0) {
-        uint32_t slot = (static_cast<uint32_t>(q) * 2654435761u) >> 22;
-        for (;;) {
-          const uint32_t cur = htab[slot];
-          if (cur == PW_OV_EMPTY) break;
-          if ((cur >> 17) == static_cast<uint32_t>(q)) {
-            e = cur & 0xFFFu;
-            break;
-          }
-          slot = (slot + 1u) & (PW_OV_HASH - 1);
-        }
-      }
-      ee[t] = e;
-    }
-    const uint32_t e0 = ee[0], e1 = ee[1], e2 = ee[2];
-    const uint32_t r00 = pal[e0 & 15u], r01 = pal[(e0 >> 4) & 15u], r02 = pal[(e0 >> 8) & 15u];
-    const uint32_t r10 = pal[e1 & 15u], r11 = pal[(e1 >> 4) & 15u], r12 = pal[(e1 >> 8) & 15u];
-    const uint32_t r20 = pal[e2 & 15u], r21 = pal[(e2 >> 4) & 15u];
-    const uint32_t d0 = r00 | (r01 << 24);
-    const uint32_t d1 = (r01 >> 8) | (r02 << 16);
-    const uint32_t d2 = (r02 >> 16) | (r10 << 8);
-    const uint32_t d3 = r11 | (r12 << 24);
-    const uint32_t d4 = (r12 >> 8) | (r20 << 16);
-    const uint32_t d5 = (r20 >> 16) | (r21 << 8);
-    const int sel = b >> 2;
-    const uint32_t s0 = sel == 0 ? d0 : (sel == 1 ? d1 : d2);
-    const uint32_t s1 = sel == 0 ? d1 : (sel == 1 ? d2 : d3);
-    const uint32_t s2 = sel == 0 ? d2 : (sel == 1 ? d3 : d4);
-    const uint32_t s3 = sel == 0 ? d3 : (sel == 1 ? d4 : d5);
-    const uint32_t s4 = sel == 0 ? d4 : d5;
-    const uint32_t bs = static_cast<uint32_t>(b & 3);
-    const uint4 o = make_uint4(__builtin_amdgcn_alignbyte(s1, s0, bs), __builtin_amdgcn_alignbyte(s2, s1, bs),
-                               __builtin_amdgcn_alignbyte(s3, s2, bs), __builtin_amdgcn_alignbyte(s4, s3, bs));
-    if (live) *reinterpret_cast<uint4*>(rec + ov.off_bytes + static_cast<int64_t>(r) * 16) = o;
-  }
-  // phase 4: publish bitmap + running counts
-  if (live) {
-    for (int w = lane; w < w32; w += PW_WAVE) {
-      reinterpret_cast<uint32_t*>(rec)[w] = bits[w];
-      reinterpret_cast<uint16_t*>(rec + ov.off_prefix)[w] = static_cast<uint16_t>(prefix[w]);
-    }
-  }
-}
-
-__global__ __launch_bounds__(64) void pw_render_ovl_kernel(CopyArgs ca, OverlayArgs ov, int32_t batch) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x;
-  const uint32_t g0 = blockIdx.x * 256u;  // first 16-byte chunk of the page
-  const uint32_t cpe = ca.chunks_per_env;
-  // g0 / cpe without an integer division: float estimate (exact to +-1 for g0 < 2^31) + correction
-  uint32_t env0 = static_cast<uint32_t>(static_cast<float>(g0) * ca.inv_cpe);
-  {
-    const int rr = static_cast<int>(g0 - env0 * cpe);
-    if (rr < 0) env0 -= 1u;
-    else if (rr >= static_cast<int>(cpe)) env0 += 1u;
-  }
-  env0 = __builtin_amdgcn_readfirstlane(env0);
-  const uint32_t last = static_cast<uint32_t>(batch) - 1u;
-  const int c_first = static_cast<int>(g0 - env0 * cpe);  // multiple of 32: chunks_per_env % 32 == 0
-  const int pid0 = ca.puzzle_id[env0];
-  uint8_t* dst = ca.obs + static_cast<int64_t>(g0) * 16 + lane * 16;
-
-  if (c_first + 256 <= static_cast<int>(ca.n_chunks)) {
-    // 13 of 14 pages: the whole page lies inside one environment's image
-    const uint8_t* src = ca.simg + static_cast<int64_t>(pid0) * ca.simg_stride + static_cast<int64_t>(c_first) * 16 + lane * 16;
-    u32x4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const u32x4*>(src + k * 1024);  // in flight first
-    const uint8_t* rec = ov.overlay + static_cast<int64_t>(env0) * ov.rec_bytes;
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(rec) + (c_first >> 5);  // 8 words cover the page
-    const uint4 wa = *reinterpret_cast<const uint4*>(words), wb = *reinterpret_cast<const uint4*>(words + 4);
-    if ((wa.x | wa.y | wa.z | wa.w | wb.x | wb.y | wb.z | wb.w) != 0u) {
-      const uint32_t wsel[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-      const uint16_t* pre = reinterpret_cast<const uint16_t*>(rec + ov.off_prefix) + (c_first >> 5);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t word = lane < 32 ? wsel[2 * k] : wsel[2 * k + 1];
-        const int bit = lane & 31;
-        if ((word >> bit) & 1u) {
-          const int rank = pre[2 * k + (lane >> 5)] + __popc(word & ((1u << bit) - 1u));
-          v[k] = *reinterpret_cast<const u32x4*>(rec + ov.off_bytes + static_cast<int64_t>(rank) * 16);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(dst + k * 1024));
-    return;
-  }
-
-  // the page holds the tail of env0 (and usually the head of env0 + 1)
-  const int split = static_cast<int>(cpe) - c_first;  // local chunk where the next environment starts
-  const bool has_second = split < 256 && env0 + 1u <= last;
-  const int pid1 = ca.puzzle_id[min(env0 + 1u, last)];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int lc = lane + 64 * k;
-    const bool second = lc >= split;
-    const int c = second ? lc - split : c_first + lc;  // chunk inside its environment
-    const bool ok = second ? (has_second && c < static_cast<int>(ca.n_chunks)) : (c < static_cast<int>(ca.n_chunks));
-    if (!ok) continue;
-    const uint8_t* rec = ov.overlay + static_cast<int64_t>(env0 + (second ? 1u : 0u)) * ov.rec_bytes;
-    const uint32_t word = reinterpret_cast<const uint32_t*>(rec)[c >> 5];
-    const int bit = c & 31;
-    const uint8_t* s = ca.simg + static_cast<int64_t>(second ? pid1 : pid0) * ca.simg_stride + static_cast<int64_t>(c) * 16;
-    if ((word >> bit) & 1u) {
-      const int rank = reinterpret_cast<const uint16_t*>(rec + ov.off_prefix)[c >> 5] + __popc(word & ((1u << bit) - 1u));
-      s = rec + ov.off_bytes + static_cast<int64_t>(rank) * 16;
-    }
-    const u32x4 v = *reinterpret_cast<const u32x4*>(s);
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + k * 1024));
-  }
-}
-
 // Generic path: any pixels_per_cell / border_width, uint8 or float32 elements.
 // One thread produces 16 bytes (16 uint8 or 4 float32 channel values) per iteration.
 template <typename T>
@@ -2098,26 +1678,19 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_generic_kernel<float>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
-  // copy+patch render path: static images of all puzzles, drawn once by the LDS kernel itself
+  // static images of all puzzles for the page-ordered kernels, drawn once by the LDS kernel itself
   e->d_simg = nullptr;
   e->simg_stride = (e->obs_bytes + 255) & ~int64_t(255);
   const char* rsel = getenv("PUSHWORLD_AMD_RENDER");
-  e->two_pass_render = rsel && std::string(rsel) == "copy";
-  e->overlay_render = rsel && std::string(rsel) == "overlay";
-  e->d_overlay = nullptr;
   e->d_dirty = nullptr;
   e->dirty_cap = 0;
-  e->overlay_cap = 0;
-  e->max_mcells = 0;
-  for (int p = 0; p < s->count; p++) e->max_mcells = std::max(e->max_mcells, static_cast<int32_t>(s->headers[p].n_mcells));
-  if (3 * e->max_mcells > PW_OV_HASH * 3 / 4) e->overlay_render = false;  // hash table too small: LDS kernel
   // Default for uint8 / ppc 3: the page-ordered kernel (static-image copy + LDS entry window), as long
   // as the static images of the whole puzzle set stay cache resident (64 MB; they are read once per
-  // observation).  PUSHWORLD_AMD_RENDER=lds|page|copy|overlay selects a path explicitly.
+  // observation).  PUSHWORLD_AMD_RENDER=lds forces the per-environment LDS kernel.
   const bool want_lds = rsel && std::string(rsel) == "lds";
-  const bool want_copy = e->fast_u8_ppc3 && !want_lds &&
+  const bool want_page = e->fast_u8_ppc3 && !want_lds &&
                          static_cast<int64_t>(s->count) * e->simg_stride <= (int64_t(64) << 20);
-  if (err == hipSuccess && want_copy) {
+  if (err == hipSuccess && want_page) {
     int32_t* d_ids = nullptr;
     int8_t* d_pos = nullptr;
     std::vector<int32_t> ids(s->count);
@@ -2158,7 +1731,6 @@ void pw_engine_destroy(PwEngine* e) {
   if (e->d_estat) (void)hipFree(e->d_estat);
   if (e->d_estat_off) (void)hipFree(e->d_estat_off);
   if (e->d_simg) (void)hipFree(e->d_simg);
-  if (e->d_overlay) (void)hipFree(e->d_overlay);
   if (e->d_dirty) (void)hipFree(e->d_dirty);
   delete e;
 }
@@ -2178,8 +1750,6 @@ int pw_engine_render_kernel(const PwEngine* e, char* buf, int cap) {
   const char* name = "pw_render_generic_kernel";
   if (e->fast_u8_ppc3) {
     if (!e->d_simg) name = "pw_render_u8_ppc3_kernel";
-    else if (e->overlay_render) name = "pw_render_ovl_kernel";
-    else if (e->two_pass_render) name = "pw_render_copy_kernel";
     else name = "pw_render_page_kernel";
   }
   const int n = static_cast<int>(strlen(name));
@@ -2250,37 +1820,7 @@ static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipS
     ca.n_chunks = static_cast<uint32_t>((e->obs_bytes + 15) / 16);
     ca.inv_cpe = 1.0f / static_cast<float>(ca.chunks_per_env);
     const uint64_t total = static_cast<uint64_t>(batch) * ca.chunks_per_env;
-    if (e->overlay_render && ca.chunks_per_env % 32u == 0u) {
-      OverlayArgs ov;
-      ov.w32 = static_cast<int32_t>(ca.chunks_per_env / 32u);
-      ov.off_prefix = (ov.w32 * 4 + 15) & ~15;
-      ov.off_bytes = ov.off_prefix + ((ov.w32 * 2 + 15) & ~15);
-      ov.max_dirty = 6 * e->max_mcells;
-      ov.rec_bytes = ov.off_bytes + static_cast<int64_t>(ov.max_dirty) * 16;
-      if (e->overlay_cap < batch) {  // first use / larger batch: (re)allocate the records
-        if (e->d_overlay) (void)hipFree(e->d_overlay);
-        e->d_overlay = nullptr;
-        e->overlay_cap = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&e->d_overlay), static_cast<size_t>(batch) * ov.rec_bytes) == hipSuccess)
-          e->overlay_cap = batch;
-      }
-      if (e->d_overlay) {
-        ov.overlay = e->d_overlay;
-        const size_t lds = static_cast<size_t>(((2 * ov.w32 + 3) & ~3) + PW_OV_HASH) * 4;
-        hipLaunchKernelGGL(pw_render_mark_kernel, dim3(static_cast<unsigned>(batch)), dim3(64), lds, st, ra, ov);
-        hipLaunchKernelGGL(pw_render_ovl_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(64), 0, st, ca, ov, batch);
-        return;
-      }
-    }
-    if (e->two_pass_render) {
-      hipLaunchKernelGGL(pw_render_copy_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(PW_COPY_THREADS), 0, st, ca);
-      if (e->np <= 16)
-        hipLaunchKernelGGL(pw_render_patch_kernel<16>, dim3(static_cast<unsigned>((batch + 15) / 16)), dim3(256), 0, st, ra);
-      else
-        hipLaunchKernelGGL(pw_render_patch_kernel<32>, dim3(static_cast<unsigned>((batch + 7) / 8)), dim3(256), 0, st, ra);
-    } else {
-      hipLaunchKernelGGL(pw_render_page_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(64), 0, st, ra, ca);
-    }
+    hipLaunchKernelGGL(pw_render_page_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(64), 0, st, ra, ca);
     return;
   }
   const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
