@@ -14,7 +14,9 @@ the step kernel (dynamics, goal, reward, done) + the render kernel (observation)
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
 ``roofline`` for the dominant kernel (render; HBM bound) measured live with HIP events on the
 launch stream, and ``cpu_baseline`` = the C restatement of the reference algorithm
-(oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample.
+(oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample; its ``python_env``
+member is the pure-Python restatement of the reference environment on one core (the reference's own
+Python env cannot travel to the GPU box).
 """
 import argparse
 import json
@@ -70,6 +72,37 @@ def cpu_baseline(paths, ids_full, max_steps, pad_h, pad_w, ppc, bw, target_secon
                   f"OpenMP over envs, {dt:.1f} s",
         "host_cpus": os.cpu_count(),
     }
+
+
+def python_env_baseline(paths, ids_full, max_steps, pad_h, pad_w, ppc, bw, target_seconds=4.0):
+    """The pure-Python restatement of the reference environment (oracle/pw_oracle.py: hash-set collision
+    tables, per-cell painter, /255 + np.pad -- the closest thing to the reference's own CPU Python env that
+    can travel to this box), one process, same puzzle mix, step + padded observation."""
+    from oracle import pw_oracle
+
+    rng = np.random.default_rng(777)
+    picks = rng.choice(len(paths), size=4, replace=False)
+    envs = []
+    t_build0 = time.perf_counter()
+    for p in picks:
+        with open(paths[p]) as f:
+            envs.append(pw_oracle.OracleEnv(pw_oracle.OraclePuzzle(f.read()), max_steps))
+    t_build = time.perf_counter() - t_build0
+    for e in envs:
+        e.reset()
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < target_seconds:
+        for e in envs:
+            state, _, term, trunc = e.step(int(rng.integers(0, 4)))
+            e.puzzle.observation_u8(state, pad_h, pad_w, ppc, bw)
+            if term or trunc:
+                e.reset()
+            steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
+            "sample": f"4 Level-1 puzzles x {steps // 4} steps, step + padded uint8 render ppc={ppc}, {dt:.1f} s; "
+                      f"collision-table construction of the 4 puzzles took {t_build:.1f} s (not included)"}
 
 
 def main():
@@ -277,6 +310,9 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(paths, ids, args.max_steps, eng.obs_shape[0] // args.ppc,
                                                    eng.obs_shape[1] // args.ppc, args.ppc, args.bw)
+                out["cpu_baseline"]["python_env"] = python_env_baseline(
+                    paths, ids, args.max_steps, eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc, args.ppc,
+                    args.bw)
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
