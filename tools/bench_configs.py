@@ -42,6 +42,38 @@ def main():
     out = {}
     dev = torch.device("cuda", 0)
 
+    # ---------------------------------------------------------------- C1: the reference's own usage pattern
+    import tempfile
+    from pushworld_amd.gym_env import PushWorldEnv
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    text = list(bd.level0_texts(("base",), "train", 1).values())[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "level_0_base_train_0.pwp")
+        with open(path, "w") as f:
+            f.write(text)
+        rng = np.random.default_rng(0)
+        for name, kw in (("default_ppc20_f32", {}), ("ppc3_bw1", dict(pixels_per_cell=3, border_width=1))):
+            env = PushWorldEnv(path, max_steps=100, **kw)
+            env.reset(seed=0)
+            n = 3000
+            acts = rng.integers(0, 4, n)
+            for a in acts[:50]:
+                env.step(int(a))
+            t0 = time.perf_counter()
+            for a in acts:
+                _, _, term, trunc, _ = env.step(int(a))
+                if term or trunc:
+                    env.reset()
+            dt = time.perf_counter() - t0
+            out["C1_gym_step_" + name] = {"steps_per_s": n / dt, "obs_shape": list(env.observation_space.shape)}
+        pz = PushWorldPuzzle(path)
+        s = pz.initial_state
+        t0 = time.perf_counter()
+        for a in acts:
+            s = pz.get_next_state(s, int(a))
+        out["C1_get_next_state_batch1"] = {"steps_per_s": n / (time.perf_counter() - t0)}
+
     # ---------------------------------------------------------------- C2
     t0 = time.perf_counter()
     l0 = bd.load_level0(("base",), "train", 1)
