@@ -48,6 +48,7 @@ struct PwEngine {
   uint16_t* d_dirty;       // per-environment dirty row interval of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)
+  bool simg_cached;        // the static images of the whole set stay cache resident: page-ordered full render
   int64_t simg_stride;     // bytes between the static images of consecutive puzzles
   uint16_t* d_estat;       // per puzzle: static zone-colour table in this engine's frame layout
   uint32_t* d_estat_off;   // byte offset of puzzle p's table in d_estat (16 B aligned)
@@ -1688,8 +1689,10 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   // as the static images of the whole puzzle set stay cache resident (64 MB; they are read once per
   // observation).  PUSHWORLD_AMD_RENDER=lds forces the per-environment LDS kernel.
   const bool want_lds = rsel && std::string(rsel) == "lds";
-  const bool want_page = e->fast_u8_ppc3 && !want_lds &&
-                         static_cast<int64_t>(s->count) * e->simg_stride <= (int64_t(64) << 20);
+  // The delta kernel reads only the rows a step changed, so for it the images may live in HBM (<= 4 GB).
+  const int64_t simg_total = static_cast<int64_t>(s->count) * e->simg_stride;
+  e->simg_cached = !want_lds && simg_total <= (int64_t(64) << 20);
+  const bool want_page = e->fast_u8_ppc3 && simg_total <= (int64_t(4) << 30);
   if (err == hipSuccess && want_page) {
     int32_t* d_ids = nullptr;
     int8_t* d_pos = nullptr;
@@ -1749,7 +1752,7 @@ int pw_engine_render_kernel(const PwEngine* e, char* buf, int cap) {
   if (!e) return pw_fail(PW_EINVAL, "null engine");
   const char* name = "pw_render_generic_kernel";
   if (e->fast_u8_ppc3) {
-    if (!e->d_simg) name = "pw_render_u8_ppc3_kernel";
+    if (!e->d_simg || !e->simg_cached) name = "pw_render_u8_ppc3_kernel";
     else name = "pw_render_page_kernel";
   }
   const int n = static_cast<int>(strlen(name));
@@ -1809,7 +1812,7 @@ static int fill_step_args(PwEngine* e, const int32_t* puzzle_id, const uint8_t* 
 static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipStream_t st) {
   // page kernels: a 4 KiB page may hold the tail of one environment and the head of the next, not
   // more -- observations smaller than a page take the per-environment LDS kernel
-  if (e->d_simg && !ra.do_step && !ra.skip_movables && ra.env_stride >= 4096) {
+  if (e->d_simg && e->simg_cached && !ra.do_step && !ra.skip_movables && ra.env_stride >= 4096) {
     CopyArgs ca;
     ca.simg = e->d_simg;
     ca.puzzle_id = ra.puzzle_id;
@@ -1927,7 +1930,7 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
   rc = fill_render_args(e, puzzle_id, pos, obs, env_stride_bytes, batch, &ra);
   if (rc != PW_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (e->d_simg && env_stride_bytes >= 4096 && !e->force_fused) {
+  if (e->d_simg && e->simg_cached && env_stride_bytes >= 4096 && !e->force_fused) {
     RolloutArgs r;
     r.s = sa;
     r.num_steps = 1;

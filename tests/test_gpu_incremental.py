@@ -92,3 +92,27 @@ def test_incremental_falls_back_for_other_settings(golden):
         for t in range(25):
             a = torch.randint(0, 4, (64,), dtype=torch.uint8, device=full.device, generator=g)
             assert torch.equal(full.step(a)[0], inc.step(a)[0]), t
+
+
+def test_incremental_with_large_pool_static_images_in_hbm(golden):
+    """860 puzzles in a 64 x 64 frame: the static images (95 MB) are no longer cache resident, so the
+    full render takes the per-environment LDS kernel while the incremental path still patches from the
+    images; results stay identical, through autoreset with re-sampling."""
+    import torch
+    from pushworld_amd.vec_env import VecPushWorld
+
+    pool = _pool(golden, list(golden.keys))
+    B, T = 2 * len(pool), 60
+    ids = np.arange(B) % len(pool)
+    kw = dict(puzzle_ids=ids, max_steps=17, pixels_per_cell=3, border_width=1, observation="uint8", pad_cells=(64, 64),
+              autoreset=True, resample=True, seed=3)
+    full = VecPushWorld(pool, B, **kw)
+    inc = VecPushWorld(pool, B, incremental=True, **kw)
+    assert full.engine.render_kernel == "pw_render_u8_ppc3_kernel"
+    g = torch.Generator(device=full.device).manual_seed(4)
+    assert torch.equal(full.reset(seed=3), inc.reset(seed=3))
+    for t in range(T):
+        a = torch.randint(0, 4, (B,), dtype=torch.uint8, device=full.device, generator=g)
+        fo, io = full.step(a), inc.step(a)
+        assert torch.equal(fo[0], io[0]), t
+        assert torch.equal(full.puzzle_id, inc.puzzle_id) and torch.equal(full.pos, inc.pos), t

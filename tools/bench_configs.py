@@ -164,6 +164,13 @@ def main():
 
     dt = timed(one5, 400, 250)  # past the first truncation wave: puzzles are shuffled across envs by then
     out["C4_render_resample"] = {"ms": dt * 1e3, "env_steps_per_s": B / dt}
+    del vec
+    vec = VecPushWorld(pool, B, max_steps=200, observation="uint8", pixels_per_cell=3, border_width=1, pad_cells=(54, 47),
+                       autoreset=True, resample=table, seed=100, incremental=True)
+    vec.reset(seed=100)
+    it[0] = 0
+    dt = timed(one5, 400, 250)
+    out["C4_render_resample_incremental"] = {"ms": dt * 1e3, "env_steps_per_s": B / dt}
     print(json.dumps(out, indent=1))
 
 
