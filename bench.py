@@ -270,7 +270,7 @@ def main():
             out["config"]["algorithmic_bytes_per_env_step"] = eng.obs_bytes + state_bytes
         # extra (not the headline): the same loop with the observation buffer maintained incrementally
         # (pw_step_render_delta: same bytes in HBM after every step, only the changed pixel rows written)
-        if obs_mode == "uint8" and args.ppc == 3 and args.bw == 1:
+        if obs_mode is not None:
             try:
                 def delta_step(t):
                     eng.step_render_delta(vec.puzzle_id, actions[t], vec.pos, vec.steps, vec.reward, vec.dgoals,

@@ -946,6 +946,7 @@ struct RenderArgs {
   float pal_f32[16][4];    // uint8 -> float32 / 255 (env_utils.py:65-72), exact IEEE division
   int32_t do_step;         // fused pw_step_render: wave 0 advances the environment first
   int32_t skip_movables;   // draw the static layers only (engine setup: static images)
+  const uint16_t* dirty_rows;  // generic kernel, pw_step_render_delta: per env cell rows to redraw (NULL = all)
   StepArgs step;
 };
 
@@ -974,12 +975,13 @@ __device__ __forceinline__ RenderLds carve_lds(unsigned char* smem, int e_bytes)
 
 // Writes the three sub-row entries of one movable cell over the static table.
 __device__ __forceinline__ void patch_cell(const PuzzleView& pv, uint16_t* E, const int16_t* spos, uint32_t c,
-                                           int estride, int c0) {
+                                           int estride, int c0, int row_lo = 0, int row_hi = PW_MAX_DIM) {
   const int obj = c >> 24;
   const int p = static_cast<uint16_t>(spos[obj]);
   const int x = static_cast<int8_t>(p & 0xff) + static_cast<int>(c & 0xff);
   const int y = static_cast<int8_t>((p >> 8) & 0xff) + static_cast<int>((c >> 8) & 0xff);
-  if (static_cast<unsigned>(x) >= static_cast<unsigned>(pv.W) || static_cast<unsigned>(y) >= static_cast<unsigned>(pv.H))
+  if (static_cast<unsigned>(x) >= static_cast<unsigned>(pv.W) || static_cast<unsigned>(y) >= static_cast<unsigned>(pv.H) ||
+      y < row_lo || y >= row_hi)
     return;
   const uint32_t kind = obj == 0 ? 3u : (obj <= pv.G ? 4u : 5u);
   const uint32_t om = (c >> 16) & 0xffu;
@@ -996,15 +998,20 @@ __device__ __forceinline__ void patch_cell(const PuzzleView& pv, uint16_t* E, co
 // the movables are patched in painter order (puzzle.py:453-458).  In an overlap-free state
 // (always, under legal play) no two movables share a cell and the patches are independent;
 // otherwise objects are applied one after the other so that a higher index wins.
+// Only the cell rows [row_lo, row_hi) are needed by the caller (incremental redraw): the rest of the table
+// is neither copied nor patched.
 __device__ __forceinline__ void build_zone_table(const RenderArgs& a, const PuzzleView& pv, int pid, int env,
-                                                 const RenderLds& l, int estride, int c0) {
+                                                 const RenderLds& l, int estride, int c0, int row_lo = 0,
+                                                 int row_hi = PW_MAX_DIM) {
   const int tid = threadIdx.x;
   const int lane = tid & (PW_WAVE - 1);
   const int n_entries = 3 * pv.H * estride;
   const int n16 = (2 * (n_entries + 3) + 15) >> 4;
   const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.estat) + a.estat_off[pid]);
   uint4* dst = reinterpret_cast<uint4*>(l.E);
-  for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
+  const int i_lo = (2 * 3 * max(row_lo, 0) * estride) >> 4;
+  const int i_hi = min(n16, (2 * (3 * min(row_hi, pv.H) * estride + 3) + 15) >> 4);
+  for (int i = i_lo + tid; i < i_hi; i += blockDim.x) dst[i] = src[i];
   if (tid < 16) l.pal[tid] = a.pal_rgb[tid];
   if (tid >= 64 && tid < 72) l.E[tid - 72] = 0;  // guard entries E[-8..-1]
   if (tid < PW_WAVE) {
@@ -1023,12 +1030,13 @@ __device__ __forceinline__ void build_zone_table(const RenderArgs& a, const Puzz
   __syncthreads();
   if (a.skip_movables) return;
   if (l.flag[0]) {
-    for (int m = tid; m < pv.n_mcells; m += blockDim.x) patch_cell(pv, l.E, l.spos, pv.mcells[m], estride, c0);
+    for (int m = tid; m < pv.n_mcells; m += blockDim.x)
+      patch_cell(pv, l.E, l.spos, pv.mcells[m], estride, c0, row_lo, row_hi);
   } else {
     for (int j = 0; j < pv.N; j++) {
       for (int m = tid; m < pv.n_mcells; m += blockDim.x) {
         const uint32_t c = pv.mcells[m];
-        if (static_cast<int>(c >> 24) == j) patch_cell(pv, l.E, l.spos, c, estride, c0);
+        if (static_cast<int>(c >> 24) == j) patch_cell(pv, l.E, l.spos, c, estride, c0, row_lo, row_hi);
       }
       __syncthreads();
     }
@@ -1430,11 +1438,23 @@ __global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_generic_kernel(Re
   extern __shared__ __align__(16) unsigned char smem[];
   const int env = blockIdx.x;
   const int tid = threadIdx.x;
+  // incremental redraw (pw_step_render_delta): only the cell rows the step changed, nothing for a blocked
+  // move, everything (frame padding included) for an environment that was reset
+  int row_lo = 0, row_hi = PW_MAX_DIM;
+  bool whole = true;
+  if (a.dirty_rows) {
+    const uint32_t d = a.dirty_rows[env];
+    row_lo = static_cast<int>(d & 0xffu);
+    row_hi = static_cast<int>(d >> 8);
+    if (row_hi <= row_lo) return;
+    whole = row_hi >= PW_MAX_DIM;
+  }
   const int pid = a.puzzle_id[env];
   const PuzzleView pv = view_of(a.hdrs, a.blob, pid);
   const int n_entries = 3 * pv.H * pv.W;
   const RenderLds l = carve_lds(smem, ((2 * (n_entries + 3) + 15) >> 4) << 4);
-  build_zone_table(a, pv, pid, env, l, pv.W, 0);
+  // a 16-byte chunk at the edge of the range reaches into the neighbouring pixel row: one more cell row each side
+  build_zone_table(a, pv, pid, env, l, pv.W, 0, whole ? 0 : row_lo - 1, whole ? PW_MAX_DIM : row_hi + 1);
   const uint16_t* E = l.E;
   const uint32_t* pal = l.pal;
 
@@ -1452,7 +1472,13 @@ __global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_generic_kernel(Re
   if (sizeof(T) == 4 && tid < 64) palf[tid] = a.pal_f32[tid >> 2][tid & 3];
   __syncthreads();
   constexpr int kPix = sizeof(T) == 1 ? 7 : 2;  // pixels a 16-byte chunk can touch
-  for (int chunk = tid; chunk < n_chunks; chunk += PW_RENDER_THREADS) {
+  int chunk_lo = 0, chunk_hi = n_chunks;
+  if (!whole) {
+    const int64_t row_b = static_cast<int64_t>(wpx) * 3 * static_cast<int>(sizeof(T));
+    chunk_lo = static_cast<int>(((pady + row_lo * ppc) * row_b) >> 4);
+    chunk_hi = min(n_chunks, static_cast<int>(((pady + min(row_hi, pv.H) * ppc) * row_b + 15) >> 4));
+  }
+  for (int chunk = chunk_lo + tid; chunk < chunk_hi; chunk += PW_RENDER_THREADS) {
     const int elem0 = chunk * kElems;
     const int pix = elem0 / 3;
     const int ch0 = elem0 - pix * 3;  // channel of the first element
@@ -1576,6 +1602,7 @@ int fill_render_args(const PwEngine* e, const int32_t* puzzle_id, const int8_t* 
   ra->obs_bytes = static_cast<int32_t>(e->obs_bytes);
   ra->do_step = 0;
   ra->skip_movables = 0;
+  ra->dirty_rows = nullptr;
   for (int i = 0; i < 16; i++) {
     ra->pal_rgb[i] = e->pal_rgb[i];
     for (int c = 0; c < 4; c++) ra->pal_f32[i][c] = e->pal_f32[i][c];
@@ -1951,8 +1978,9 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
                          double* reward, int8_t* dgoals, uint8_t* terminated, uint8_t* truncated, void* obs,
                          int64_t env_stride_bytes, int32_t batch, uint32_t flags, void* stream) {
   if (!e) return pw_fail(PW_EINVAL, "null engine");
-  // needs the static images, the uint8 / ppc 3 entry layout and the group step kernel; otherwise full render
-  if (!e->d_simg || !e->fast_u8_ppc3 || e->step_kernel != 0 || e->force_fused)
+  // uint8 / ppc 3 engines patch from their static images, every other engine redraws the changed rows with
+  // the generic LDS kernel; both need the group step kernel (it reports the rows).  Otherwise: full render.
+  if ((e->fast_u8_ppc3 && !e->d_simg) || e->step_kernel != 0 || e->force_fused)
     return pw_step_render(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, obs, env_stride_bytes,
                           batch, flags, stream);
   RenderArgs ra;
@@ -1979,6 +2007,15 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
   r.term_hist = nullptr;
   r.trunc_hist = nullptr;
   launch_group(e, r, batch, st);
+  if (!e->fast_u8_ppc3) {
+    ra.dirty_rows = e->d_dirty;
+    const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
+    if (e->cfg.obs_dtype == PW_OBS_U8)
+      hipLaunchKernelGGL(pw_render_generic_kernel<uint8_t>, grid, block, e->render_lds, st, ra);
+    else
+      hipLaunchKernelGGL(pw_render_generic_kernel<float>, grid, block, e->render_lds, st, ra);
+    return check_launch("pw_step_render_delta");
+  }
   CopyArgs ca;
   ca.simg = e->d_simg;
   ca.puzzle_id = puzzle_id;
