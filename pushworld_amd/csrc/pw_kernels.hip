@@ -45,7 +45,7 @@ struct PwEngine {
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
   int step_kernel;         // 0 group (default), 1 wavefront per env, 2 lane per env (PUSHWORLD_AMD_STEP)
   bool force_fused;        // PUSHWORLD_AMD_FUSED=1: pw_step_render always uses the single fused launch
-  uint16_t* d_dirty;       // per-environment dirty row interval of pw_step_render_delta (grown on demand)
+  uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)
   bool simg_cached;        // the static images of the whole set stay cache resident: page-ordered full render
@@ -293,7 +293,8 @@ struct StepArgs {
   int32_t max_steps;
   uint32_t flags;
   int32_t np;
-  uint16_t* dirty;  // optional [batch]: cell rows the step changed, lo | hi << 8 (0 = none); group kernel only
+  uint32_t* dirty;  // optional [batch]: cell rows the step changed, lo | hi << 8 | puzzle height << 16
+                    // (lo = hi = 0: none); group kernel only
 };
 
 // One wavefront advances one environment (all lanes of the wave must call this).
@@ -718,6 +719,30 @@ __global__ __launch_bounds__(256) void pw_rollout_lane_kernel(RolloutArgs r) {
   if (a.dgoals) a.dgoals[env] = static_cast<int8_t>(s.dgoals);
 }
 
+// The agent's wall test spread over the lanes of its group: lane k tests grid row y - 1 + k of the window
+// the agent can reach (h + 2 rows), the verdict is two ballots.  ~6x fewer VALU cycles than one lane walking
+// the window (the step kernel is VALU bound, profiles/r01_sq2.txt).  Wave-uniform fallback for agents taller
+// than the group.
+template <int GS>
+__device__ __forceinline__ bool group_agent_blocked(const LanePuzzle& p, int xy, uint32_t ot, int lj, int gbase,
+                                                    unsigned long long gmask, bool play, int act) {
+  const LaneObj ag = lane_obj(static_cast<uint32_t>(__shfl(static_cast<int>(ot), gbase, PW_WAVE)), __shfl(xy, gbase, PW_WAVE));
+  if (__ballot(ag.h + 2 > GS) != 0ull) {
+    bool blk = false;
+    if (play && lj == 0) blk = lane_agent_blocked(p, ag, act);
+    return (__ballot(blk) & gmask) != 0ull;
+  }
+  const int yy = ag.y - 1 + lj;
+  bool hit = false, now = false;
+  if (play && lj < ag.h + 2 && static_cast<unsigned>(yy) < static_cast<unsigned>(p.H)) {
+    const uint64_t g = p.awall[yy];
+    now = (lane_row(p, ag, yy) & g) != 0ull;
+    hit = (lane_row_shifted(p, ag, yy, act) & g) != 0ull;
+  }
+  const unsigned long long hm = __ballot(hit) & gmask, nm = __ballot(now) & gmask;
+  return hm != 0ull && nm == 0ull;
+}
+
 // ------------------------------------------------------------------------------------
 // K1d step / rollout, GS lanes per environment (lane j of a group = movable j)
 //
@@ -774,10 +799,8 @@ __global__ __launch_bounds__(256) void pw_step_group_kernel(RolloutArgs r) {
     const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
     const LaneObj me = lane_obj(ot, xy);
 
-    // agent against walls + agent walls (puzzle.py:353), evaluated by the group's lane 0
-    bool agent_blk = false;
-    if (play && lj == 0) agent_blk = lane_agent_blocked(p, me, act);
-    bool dead = (__ballot(agent_blk) & gmask) != 0ull;
+    // agent against walls + agent walls (puzzle.py:353)
+    bool dead = group_agent_blocked<GS>(p, xy, ot, lj, gbase, gmask, play, act);
     uint32_t pushed = 1u, frontier = 0u;
     int cur = 0;
     bool active = play && !dead;
@@ -862,7 +885,7 @@ __global__ __launch_bounds__(256) void pw_step_group_kernel(RolloutArgs r) {
     a.trunc[env] = static_cast<uint8_t>(trunc);
     if (a.dirty) {
       const int lo = max(row_lo, 0), hi = min(row_hi, PW_MAX_DIM);
-      a.dirty[env] = hi > lo ? static_cast<uint16_t>(lo | (hi << 8)) : static_cast<uint16_t>(0);
+      a.dirty[env] = hi > lo ? static_cast<uint32_t>(lo | (hi << 8) | (p.H << 16)) : 0u;
     }
     if (any_played) {
       a.steps[env] = steps;
@@ -946,7 +969,7 @@ struct RenderArgs {
   float pal_f32[16][4];    // uint8 -> float32 / 255 (env_utils.py:65-72), exact IEEE division
   int32_t do_step;         // fused pw_step_render: wave 0 advances the environment first
   int32_t skip_movables;   // draw the static layers only (engine setup: static images)
-  const uint16_t* dirty_rows;  // generic kernel, pw_step_render_delta: per env cell rows to redraw (NULL = all)
+  const uint32_t* dirty_rows;  // generic kernel, pw_step_render_delta: per env cell rows to redraw (NULL = all)
   StepArgs step;
 };
 
@@ -1376,20 +1399,20 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
 // window over ALL movables that reach into the segment), 4 KiB at a time.  Environments that were
 // reset carry the full interval and are redrawn completely.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyArgs ca, const uint16_t* dirty_rows) {
+__global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyArgs ca, const uint32_t* dirty_rows) {
   typedef pw_u32x4 u32x4;
   __shared__ uint32_t pal[16];
   __shared__ uint32_t dirty[8];
   __shared__ __align__(16) uint32_t win0[PW_PAGE_ENTRIES];
   const int lane = threadIdx.x;
   const uint32_t env = blockIdx.x;
+  // first level of loads, all independent: the record (rows + puzzle height), positions, puzzle id
   const uint32_t d = dirty_rows[env];
-  const int ylo = static_cast<int>(d & 0xffu), yhi_raw = static_cast<int>(d >> 8);
-  if (yhi_raw <= ylo) return;  // nothing moved: the buffer is already right
   const int xy = page_load_xy(a, env, lane);
   const int pid = a.puzzle_id[env];
-  const PwPuzzleHeader* h = a.hdrs + pid;
-  const int H = h->H;
+  const int ylo = static_cast<int>(d & 0xffu), yhi_raw = static_cast<int>((d >> 8) & 0xffu);
+  if (yhi_raw <= ylo) return;  // nothing moved: the buffer is already right
+  const int H = static_cast<int>(d >> 16);  // from the record: the chunk range needs no header load
   const int pady = (a.pad_h - H) * 3 / 2;
   const int row_bytes = 9 * a.pad_w;
   const int yhi = min(yhi_raw, H);
@@ -1445,7 +1468,7 @@ __global__ __launch_bounds__(PW_RENDER_THREADS) void pw_render_generic_kernel(Re
   if (a.dirty_rows) {
     const uint32_t d = a.dirty_rows[env];
     row_lo = static_cast<int>(d & 0xffu);
-    row_hi = static_cast<int>(d >> 8);
+    row_hi = static_cast<int>((d >> 8) & 0xffu);
     if (row_hi <= row_lo) return;
     whole = row_hi >= PW_MAX_DIM;
   }
@@ -1994,7 +2017,7 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
     if (e->d_dirty) (void)hipFree(e->d_dirty);
     e->d_dirty = nullptr;
     e->dirty_cap = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&e->d_dirty), static_cast<size_t>(batch) * sizeof(uint16_t)) != hipSuccess)
+    if (hipMalloc(reinterpret_cast<void**>(&e->d_dirty), static_cast<size_t>(batch) * sizeof(uint32_t)) != hipSuccess)
       return pw_fail(PW_ENOMEM, "pw_step_render_delta: cannot allocate the dirty-row buffer");
     e->dirty_cap = batch;
   }
