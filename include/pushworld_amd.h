@@ -47,6 +47,7 @@ extern "C" {
 #define PW_ELIMIT (-4)     /* puzzle exceeds engine limits (W,H<=64, N<=32)   -> ValueError    */
 #define PW_EDEVICE (-5)    /* HIP runtime error / no device                   -> RuntimeError  */
 #define PW_ENOMEM (-6)
+#define PW_EELEMENT (-7)   /* empty element name ("M1++G1"): puzzle.py:218 elem_id[0]  -> IndexError     */
 
 /* object orderings (SURVEY trap T1) */
 #define PW_ORDER_PYTHON 0  /* puzzle.py:170-257: agent, goals descending, rest in file order */

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PUSHWORLD_AMD_LIB") or os.path.join(_HERE, "lib", "libpushworld_amd.so")
 
 PW_OK = 0
-PW_EINVAL, PW_EPARSE, PW_EGOAL, PW_ELIMIT, PW_EDEVICE, PW_ENOMEM = -1, -2, -3, -4, -5, -6
+PW_EINVAL, PW_EPARSE, PW_EGOAL, PW_ELIMIT, PW_EDEVICE, PW_ENOMEM, PW_EELEMENT = -1, -2, -3, -4, -5, -6, -7
 ORDER_PYTHON, ORDER_CPP = 0, 1
 OBS_U8, OBS_F32 = 0, 1
 STEP_AUTORESET = 1
@@ -157,6 +157,8 @@ def check(rc: int) -> int:
         raise AssertionError(msg)
     if rc == PW_ENOMEM:
         raise MemoryError(msg)
+    if rc == PW_EELEMENT:
+        raise IndexError(msg)
     raise RuntimeError(msg)
 
 

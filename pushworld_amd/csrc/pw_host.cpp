@@ -67,6 +67,7 @@ int parse_puzzle(const char* text, size_t len, int order, PwPuzzle* pz) {
   if (order != PW_ORDER_PYTHON && order != PW_ORDER_CPP)
     return pw_fail(PW_EINVAL, "order must be PW_ORDER_PYTHON or PW_ORDER_CPP");
 
+  bool saw_empty_element = false;
   // element id -> absolute cells; `first_seen` keeps the file order of appearance, which
   // is the dict insertion order the Python reference iterates (puzzle.py:235-237).
   std::map<std::string, std::set<PwCell>> cells;
@@ -96,7 +97,11 @@ int parse_puzzle(const char* text, size_t len, int order, PwPuzzle* pz) {
         std::string id = tok.substr(s, e - s);
         s = e + 1;
         for (auto& ch : id) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
-        if (id.empty() || id == ".") continue;
+        if (id.empty()) {  // "M1++G1", "M1+", "+": the reference stores the element "" (see below)
+          saw_empty_element = true;
+          continue;
+        }
+        if (id == ".") continue;
         if (!cells.count(id)) first_seen.push_back(id);
         cells[id].insert({col, n_rows});
       }
@@ -145,6 +150,10 @@ int parse_puzzle(const char* text, size_t len, int order, PwPuzzle* pz) {
       if (kv.first[0] == 'm' && !listed(kv.first)) rest.push_back(kv.first);  // ascending
     for (const auto& id : rest) movables.push_back(id);
   }
+  // puzzle.py:218 evaluates elem_id[0] for every element in descending order; "" sorts last, so the
+  // reference raises IndexError only after every goal has found its movable
+  if (saw_empty_element)
+    return pw_fail(PW_EELEMENT, "empty element name in a cell ('+' without a name on one side)");
   if (movables.size() > PW_MAX_OBJECTS)
     return pw_fail(PW_ELIMIT, "puzzle has " + std::to_string(movables.size()) +
                                   " movables; the engine supports at most 32");

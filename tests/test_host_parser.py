@@ -236,3 +236,40 @@ def test_packed_set_file_round_trip_and_rejects_corruption(golden, tmp_path):
     for byte in evil[64:]:
         h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     assert struct.pack("<Q", h) == raw[40:48]
+
+
+def test_parser_fuzz_vectors_from_the_reference():
+    """600 random puzzle texts (ragged rows, unknown / empty / duplicated element names, blank lines, tabs,
+    CRLF, goals without movables ...) with the reference's verdict (tests/golden/make_parser_fuzz_golden.py):
+    the C++ parser behind the C ABI and the oracle raise the same exception type or produce the same
+    dimensions, state, goals, object cells, walls and agent walls."""
+    import json
+
+    from oracle import pw_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    with open(os.path.join(ROOT, "tests", "golden", "golden_parser_fuzz.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 600
+    errors = {"ValueError": ValueError, "AssertionError": AssertionError, "IndexError": IndexError}
+    n_ok = 0
+    for i, case in enumerate(cases):
+        text, want = case["text"], case["result"]
+        if "error" in want:
+            with pytest.raises(errors[want["error"]]):
+                _capi.ParsedPuzzle(text)
+            with pytest.raises(errors[want["error"]]):
+                pw_oracle.OraclePuzzle(text, build_tables=False)
+            continue
+        n_ok += 1
+        o = pw_oracle.OraclePuzzle(text, build_tables=False)
+        p = _capi.ParsedPuzzle(text)
+        assert [p.width, p.height] == want["dimensions"] == [o.width, o.height], i
+        assert [list(xy) for xy in p.initial_state] == want["initial_state"] == [list(xy) for xy in o.initial_state], i
+        assert [list(xy) for xy in p.goal_state] == want["goal_state"] == [list(xy) for xy in o.goal_state], i
+        assert [sorted(map(list, c)) for c in p.object_cells] == want["object_cells"], i
+        assert [sorted(map(list, s)) for s in o.shapes] == want["object_cells"], i
+        assert sorted(map(list, p.wall_cells)) == want["walls"] == sorted(map(list, o.wall_cells)), i
+        # the reference property returns AW u W (SURVEY trap T2); the C ABI exposes the raw "aw" cells
+        assert sorted(map(list, o.agent_wall_cells)) == want["agent_walls"], i
+    assert n_ok > 100
