@@ -743,6 +743,39 @@ __device__ __forceinline__ bool group_agent_blocked(const LanePuzzle& p, int xy,
   return hm != 0ull && nm == 0ull;
 }
 
+// The push set of one action for the environment / state held by a lane group (lane j = movable j):
+// agent wall test, then the fixed point "some member pushes my object" by ballots; any wall-blocked member
+// kills the move (transitive stopping, puzzle.py:376-379).  Returns the mask of the objects that move
+// (bit 0 = agent), 0 when nothing moves.  Shared by the step, planner-expansion and search kernels.
+template <int GS>
+__device__ __forceinline__ uint32_t group_push_set(const LanePuzzle& p, int xy, uint32_t ot, const LaneObj& me, int lj,
+                                                   int gbase, unsigned long long gmask, bool play, int act, int dx, int dy) {
+  bool dead = group_agent_blocked<GS>(p, xy, ot, lj, gbase, gmask, play, act);
+  uint32_t pushed = 1u, frontier = 0u;
+  int cur = 0;
+  bool active = play && !dead;
+  while (__ballot(active) != 0ull) {  // every lane tests the group's current pusher against its own object
+    const int pxy = __shfl(xy, gbase + cur, PW_WAVE);
+    const uint32_t pot = static_cast<uint32_t>(__shfl(static_cast<int>(ot), gbase + cur, PW_WAVE));
+    bool hit = false, blk = false;
+    if (active && lj >= 1 && lj < p.N && !((pushed >> lj) & 1u)) {
+      hit = lane_pushes(p, lane_obj(pot, pxy), me, act, dx, dy);
+      if (hit) blk = lane_blocked(p, me, p.wall, act);
+    }
+    const unsigned long long hm = __ballot(hit), bk = __ballot(blk);
+    const uint32_t fresh = static_cast<uint32_t>((hm & gmask) >> gbase);
+    if ((bk & gmask) != 0ull) dead = true;
+    pushed |= fresh;
+    frontier |= fresh;
+    active = active && !dead && frontier != 0u;
+    if (active) {
+      cur = __ffs(frontier) - 1;
+      frontier &= frontier - 1u;
+    }
+  }
+  return (play && !dead) ? pushed : 0u;
+}
+
 // ------------------------------------------------------------------------------------
 // K1d step / rollout, GS lanes per environment (lane j of a group = movable j)
 //
@@ -799,32 +832,7 @@ __global__ __launch_bounds__(256) void pw_step_group_kernel(RolloutArgs r) {
     const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
     const LaneObj me = lane_obj(ot, xy);
 
-    // agent against walls + agent walls (puzzle.py:353)
-    bool dead = group_agent_blocked<GS>(p, xy, ot, lj, gbase, gmask, play, act);
-    uint32_t pushed = 1u, frontier = 0u;
-    int cur = 0;
-    bool active = play && !dead;
-    // push-set fixed point: every lane tests the group's current pusher against its own object
-    while (__ballot(active) != 0ull) {
-      const int pxy = __shfl(xy, gbase + cur, PW_WAVE);
-      const uint32_t pot = static_cast<uint32_t>(__shfl(static_cast<int>(ot), gbase + cur, PW_WAVE));
-      bool hit = false, blk = false;
-      if (active && lj >= 1 && lj < N && !((pushed >> lj) & 1u)) {
-        hit = lane_pushes(p, lane_obj(pot, pxy), me, act, dx, dy);
-        if (hit) blk = lane_blocked(p, me, p.wall, act);  // transitive stopping (puzzle.py:376-379)
-      }
-      const unsigned long long hm = __ballot(hit), bk = __ballot(blk);
-      const uint32_t fresh = static_cast<uint32_t>((hm & gmask) >> gbase);
-      if ((bk & gmask) != 0ull) dead = true;
-      pushed |= fresh;
-      frontier |= fresh;
-      active = active && !dead && frontier != 0u;
-      if (active) {
-        cur = __ffs(frontier) - 1;
-        frontier &= frontier - 1u;
-      }
-    }
-    const uint32_t moved = (play && !dead) ? pushed : 0u;
+    const uint32_t moved = group_push_set<GS>(p, xy, ot, me, lj, gbase, gmask, play, act, dx, dy);
 
     // displaced state + goal bookkeeping (puzzle.py:384-411)
     int nxy = xy;
@@ -909,41 +917,57 @@ struct ExpandArgs {
   int32_t num_states;
 };
 
+template <int GS>
 __global__ __launch_bounds__(256) void pw_expand4_kernel(ExpandArgs a) {
+  constexpr int kGroups = 256 / GS;
   const int lane = threadIdx.x & (PW_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-  const int sidx = blockIdx.x * (256 / PW_WAVE) + wave;
-  if (sidx >= a.num_states) return;
-  const PuzzleView pv = view_of(a.hdrs, a.blob, a.puzzle);
-  const int N = pv.N;
+  const int lj = threadIdx.x & (GS - 1);
+  const int gbase = lane & ~(GS - 1);
+  const unsigned long long gmask = ((1ull << (GS - 1) << 1) - 1ull) << gbase;
+  const int sidx = blockIdx.x * kGroups + static_cast<int>(threadIdx.x) / GS;
+  const bool live = sidx < a.num_states;
+  const int64_t sg = live ? sidx : 0;
 
-  // Position2D = x * 10000 + y (pushworld_puzzle.h:32-37)
-  int p2d = 0, x = 0, y = 0;
-  if (lane < N) {
-    p2d = a.states[static_cast<int64_t>(sidx) * N + lane];
-    x = p2d / PW_POSITION_LIMIT;
-    y = p2d - x * PW_POSITION_LIMIT;
+  LanePuzzle p;
+  const PwPuzzleHeader* h = a.hdrs + a.puzzle;
+  p.h = h;
+  {
+    const uint8_t* b = a.blob + h->base;
+    p.wall = reinterpret_cast<const uint64_t*>(b + h->off_wall);
+    p.awall = reinterpret_cast<const uint64_t*>(b + h->off_awall);
+    p.shapes = reinterpret_cast<const uint64_t*>(b + h->off_shapes);
   }
-  const int xy = (x & 0xff) | ((y & 0xff) << 8);
-  const EnvBoards b = load_boards(pv, xy, lane);
-
-  const bool is_goal_lane = lane >= 1 && lane <= pv.G;
-  int g2d = 0;
+  p.H = h->H;
+  p.N = h->N;
+  p.G = h->G;
+  const int N = p.N;
+  // Position2D = x * 10000 + y (pushworld_puzzle.h:32-37)
+  int p2d = 0, xy = 0;
+  if (lj < N) {
+    p2d = a.states[sg * N + lj];
+    const int x = p2d / PW_POSITION_LIMIT;
+    xy = (x & 0xff) | (((p2d - x * PW_POSITION_LIMIT) & 0xff) << 8);
+  }
+  const uint32_t ot = (lj < N) ? reinterpret_cast<const uint32_t*>(h->objtab)[lj] : 0u;
+  const LaneObj me = lane_obj(ot, xy);
+  const bool is_goal_lane = lj >= 1 && lj <= p.G;
+  int g2d = -1;
   if (is_goal_lane) {
-    const int gxy = reinterpret_cast<const uint16_t*>(pv.h->goal)[lane - 1];
+    const int gxy = reinterpret_cast<const uint16_t*>(h->goal)[lj - 1];
     g2d = (gxy & 0xff) * PW_POSITION_LIMIT + ((gxy >> 8) & 0xff);
   }
-
+#pragma unroll 1
   for (int act = 0; act < 4; act++) {
-    const uint32_t pushed = push_closure(pv, b, xy, act, lane);
-    const int disp = act == 0 ? -PW_POSITION_LIMIT : (act == 1 ? PW_POSITION_LIMIT : (act == 2 ? -1 : 1));
-    const int n2d = p2d + (((pushed >> lane) & 1u) ? disp : 0);
-    const int64_t o = static_cast<int64_t>(sidx) * 4 + act;
-    if (lane < N) a.succ[o * N + lane] = n2d;
-    const int hits = __popcll(__ballot(is_goal_lane && n2d == g2d));
-    if (lane == 0) {
-      a.moved[o] = pushed;
-      a.goal[o] = hits == pv.G ? 1 : 0;
+    const int dx = act == 0 ? -1 : (act == 1 ? 1 : 0);
+    const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
+    const uint32_t pushed = group_push_set<GS>(p, xy, ot, me, lj, gbase, gmask, live, act, dx, dy);
+    const int n2d = p2d + (((pushed >> lj) & 1u) ? dx * PW_POSITION_LIMIT + dy : 0);
+    const int64_t o = sg * 4 + act;
+    if (live && lj < N) a.succ[o * N + lj] = n2d;
+    const int hits = __popcll(__ballot(is_goal_lane && n2d == g2d) & gmask);
+    if (live && lj == 0) {
+      a.moved[o] = pushed;  // = moved_object_indices (pushworld_puzzle.cc:446-457); empty when blocked
+      a.goal[o] = hits == p.G ? 1 : 0;
     }
   }
 }
@@ -2058,8 +2082,12 @@ int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ
   if (puzzle < 0 || puzzle >= e->set->count) return pw_fail(PW_EINVAL, "puzzle index out of range");
   if (num_states <= 0) return PW_OK;
   ExpandArgs a{e->set->d_headers, e->set->d_blob, puzzle, states, succ, moved, goal, num_states};
-  const unsigned blocks = static_cast<unsigned>((num_states + 3) / 4);
-  hipLaunchKernelGGL(pw_expand4_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  if (e->set->headers[puzzle].N <= 16)
+    hipLaunchKernelGGL(pw_expand4_kernel<16>, dim3(static_cast<unsigned>((num_states + 15) / 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(pw_expand4_kernel<32>, dim3(static_cast<unsigned>((num_states + 7) / 8)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
   return check_launch("pw_expand4");
 }
 
