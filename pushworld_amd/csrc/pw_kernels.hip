@@ -387,8 +387,9 @@ __global__ __launch_bounds__(256) void pw_step_kernel(StepArgs a) {
 // Same predicate as the wavefront kernel, evaluated by a single lane on the few rows where two
 // bounding boxes can meet: object rows are fetched from the packed shape rows (L1 hits, the
 // lanes of a wave mostly share a puzzle) instead of being spread over a wave.  64x less
-// ALU work and coalesced per-env outputs; used by pw_step, while the fused step+render launch
-// and pw_expand4 keep the wavefront formulation.
+// ALU work and coalesced per-env outputs.  These row helpers are what the lane-group kernels further down
+// (pw_step / pw_rollout default, pw_expand4, pw_search) are built from; only the fused step+render launch
+// keeps the wavefront formulation.
 // ------------------------------------------------------------------------------------
 struct LanePuzzle {
   const PwPuzzleHeader* h;
