@@ -47,6 +47,7 @@ def bfs(puzzle, max_states):
     "cpptest:necessary_transitive_pushing3.pwp", "cpptest:multiple_goals.pwp", "cpptest:file_parsing.pwp",
     "bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp", "bench:level4/Four Pistons.pwp",
     "bench:level1/Pulling.pwp", "bench:level3/Armor.pwp",
+    "bench:level2/Clean Sweep.pwp",  # 19 movables: the 32-lane instantiation
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle

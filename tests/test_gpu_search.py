@@ -150,17 +150,18 @@ def test_bfs_store_overflow_and_errors(golden):
     bfs.close()
 
 
-def test_bfs_large_layer_matches_host_prefix(golden):
+@pytest.mark.parametrize("key,cap", [("bench:level1/2 Obstacle.pwp", 150000), ("bench:level2/Clean Sweep.pwp", 40000)])
+def test_bfs_large_layer_matches_host_prefix(golden, key, cap):
     """'2 Obstacle' explored to 150 000 states with the default pass size: the first 150 000 states of
-    the sequential search, in the same order (exercises multi-block scans and hash-table growth)."""
+    the sequential search, in the same order (exercises multi-block scans and hash-table growth);
+    'Clean Sweep' has 19 movables (32-lane groups, 10 words per state)."""
     from oracle import c_oracle
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
 
-    text = golden.text("bench:level1/2 Obstacle.pwp")
+    text = golden.text(key)
     oz = c_oracle.COraclePuzzle(text)
     pz = PushWorldPuzzle(text=text)
-    cap = 150000
     bfs = BreadthFirstSearch(pz, max_states=cap)
     bfs.begin()
     try:
@@ -285,7 +286,7 @@ def test_width_limited_search_equals_host_model(golden, width, chunk, monkeypatc
     else:
         monkeypatch.delenv("PUSHWORLD_AMD_SEARCH_CHUNK", raising=False)
     keys = CASES + ["bench:level1/2 Obstacle.pwp", "bench:level1/Choose Wisely.pwp", "bench:level2/Pull Dont Push.pwp",
-                    "cpptest:file_parsing.pwp"]
+                    "cpptest:file_parsing.pwp", "bench:level2/Clean Sweep.pwp"]
     n_checked = n_pruned = n_solved = 0
     for key in keys:
         if key not in golden.meta:
