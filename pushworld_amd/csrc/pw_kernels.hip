@@ -749,9 +749,9 @@ __device__ __forceinline__ bool group_agent_blocked(const LanePuzzle& p, int xy,
 // kills the move (transitive stopping, puzzle.py:376-379).  Returns the mask of the objects that move
 // (bit 0 = agent), 0 when nothing moves.  Shared by the step, planner-expansion and search kernels.
 template <int GS>
-__device__ __forceinline__ uint32_t group_push_set(const LanePuzzle& p, int xy, uint32_t ot, const LaneObj& me, int lj,
-                                                   int gbase, unsigned long long gmask, bool play, int act, int dx, int dy) {
-  bool dead = group_agent_blocked<GS>(p, xy, ot, lj, gbase, gmask, play, act);
+__device__ __forceinline__ uint32_t group_push_closure(const LanePuzzle& p, int xy, uint32_t ot, const LaneObj& me, int lj,
+                                                       int gbase, unsigned long long gmask, bool play, bool dead, int act,
+                                                       int dx, int dy) {
   uint32_t pushed = 1u, frontier = 0u;
   int cur = 0;
   bool active = play && !dead;
@@ -775,6 +775,44 @@ __device__ __forceinline__ uint32_t group_push_set(const LanePuzzle& p, int xy, 
     }
   }
   return (play && !dead) ? pushed : 0u;
+}
+
+template <int GS>
+__device__ __forceinline__ uint32_t group_push_set(const LanePuzzle& p, int xy, uint32_t ot, const LaneObj& me, int lj,
+                                                   int gbase, unsigned long long gmask, bool play, int act, int dx, int dy) {
+  const bool dead = group_agent_blocked<GS>(p, xy, ot, lj, gbase, gmask, play, act);
+  return group_push_closure<GS>(p, xy, ot, me, lj, gbase, gmask, play, dead, act, dx, dy);
+}
+
+// The agent's wall test for all four actions of one state (planner expansion): the window rows are loaded
+// once, LEFT / RIGHT are in-lane shifts, UP / DOWN take the neighbouring lane's row.  Bit a of the result =
+// action a is blocked.  Same verdicts as four group_agent_blocked calls.
+template <int GS>
+__device__ __forceinline__ uint32_t group_agent_blocked4(const LanePuzzle& p, int xy, uint32_t ot, int lj, int gbase,
+                                                         unsigned long long gmask, bool play) {
+  const LaneObj ag = lane_obj(static_cast<uint32_t>(__shfl(static_cast<int>(ot), gbase, PW_WAVE)), __shfl(xy, gbase, PW_WAVE));
+  if (__ballot(ag.h + 2 > GS) != 0ull) {
+    uint32_t m = 0;
+    for (int act = 0; act < 4; act++)
+      if (group_agent_blocked<GS>(p, xy, ot, lj, gbase, gmask, play, act)) m |= 1u << act;
+    return m;
+  }
+  const int yy = ag.y - 1 + lj;
+  const bool in_win = play && lj < ag.h + 2;
+  const uint64_t sh = in_win ? lane_row(p, ag, yy) : 0ull;  // 0 outside the object's rows / the 64-row frame
+  const uint64_t g = (in_win && static_cast<unsigned>(yy) < static_cast<unsigned>(p.H)) ? p.awall[yy] : 0ull;
+  // UP: new row yy holds old row yy + 1 (next lane); DOWN: old row yy - 1 (previous lane)
+  uint64_t up = __shfl_down(sh, 1, PW_WAVE), dn = __shfl_up(sh, 1, PW_WAVE);
+  if (lj == GS - 1 || yy == 63) up = 0ull;
+  if (lj == 0 || yy == 0) dn = 0ull;
+  const bool now = (sh & g) != 0ull;
+  const bool overlapping = (__ballot(now) & gmask) != 0ull;  // already inside a wall: never "blocked" (puzzle.py:562)
+  uint32_t m = 0;
+  if ((__ballot(((sh >> 1) & g) != 0ull) & gmask) != 0ull) m |= 1u;
+  if ((__ballot(((sh << 1) & g) != 0ull) & gmask) != 0ull) m |= 2u;
+  if ((__ballot((up & g) != 0ull) & gmask) != 0ull) m |= 4u;
+  if ((__ballot((dn & g) != 0ull) & gmask) != 0ull) m |= 8u;
+  return overlapping ? 0u : m;
 }
 
 // ------------------------------------------------------------------------------------
@@ -957,11 +995,13 @@ __global__ __launch_bounds__(256) void pw_expand4_kernel(ExpandArgs a) {
     const int gxy = reinterpret_cast<const uint16_t*>(h->goal)[lj - 1];
     g2d = (gxy & 0xff) * PW_POSITION_LIMIT + ((gxy >> 8) & 0xff);
   }
+  const uint32_t agent_blocked = group_agent_blocked4<GS>(p, xy, ot, lj, gbase, gmask, live);
 #pragma unroll 1
   for (int act = 0; act < 4; act++) {
     const int dx = act == 0 ? -1 : (act == 1 ? 1 : 0);
     const int dy = act == 2 ? -1 : (act == 3 ? 1 : 0);
-    const uint32_t pushed = group_push_set<GS>(p, xy, ot, me, lj, gbase, gmask, live, act, dx, dy);
+    const uint32_t pushed =
+        group_push_closure<GS>(p, xy, ot, me, lj, gbase, gmask, live, ((agent_blocked >> act) & 1u) != 0u, act, dx, dy);
     const int n2d = p2d + (((pushed >> lj) & 1u) ? dx * PW_POSITION_LIMIT + dy : 0);
     const int64_t o = sg * 4 + act;
     if (live && lj < N) a.succ[o * N + lj] = n2d;
