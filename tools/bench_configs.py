@@ -91,6 +91,30 @@ def main():
     out["C2_step_per_launch"] = {"ms": dt * 1e3, "env_steps_per_s": 4096 / dt}
     dt = timed(lambda: vec.rollout(acts), 200, 5)
     out["C2_rollout_64_per_launch"] = {"ms": dt * 1e3, "env_steps_per_s": 4096 * T / dt}
+    # the same 64 single-step launches captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(T):
+            vec.step(acts[k])
+    dt = timed(g.replay, 200, 5)
+    out["C2_hipgraph_64_step_launches"] = {"ms": dt * 1e3, "env_steps_per_s": 4096 * T / dt}
+    vec_r = VecPushWorld(l0, 4096, max_steps=100, observation="uint8", pixels_per_cell=3, border_width=1, autoreset=True,
+                         incremental=True)
+    vec_r.reset()
+    for k in range(4):
+        vec_r.step(acts[k])
+
+    def loop_r():
+        for k in range(T):
+            vec_r.step(acts[k])
+
+    dt = timed(loop_r, 20, 2)
+    out["C2_with_incremental_render_eager"] = {"ms_per_step": dt * 1e3 / T, "env_steps_per_s": 4096 * T / dt}
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        loop_r()
+    dt = timed(g2.replay, 50, 3)
+    out["C2_with_incremental_render_hipgraph"] = {"ms_per_step": dt * 1e3 / T, "env_steps_per_s": 4096 * T / dt}
 
     # ---------------------------------------------------------------- C4 shard
     t0 = time.perf_counter()
