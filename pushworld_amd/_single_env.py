@@ -65,18 +65,33 @@ class SingleEnvCore:
         self._engine = _capi.Engine(self._pset, max_steps, pixels_per_cell, border_width, _capi.OBS_F32,
                                     self._max_cell_height, self._max_cell_width)
         self._render_engines = {}
-        st = self._engine.alloc_state(1)
-        self._buf = st
-        self._pid = torch.zeros((1,), dtype=torch.int32, device=self._engine.device)
-        self._act = torch.zeros((1,), dtype=torch.uint8, device=self._engine.device)
+        # all per-step scalars and the positions live in ONE small device buffer (typed views into it), and
+        # come back to the host together with the observation in a single stream synchronisation per step
+        dev_t = self._engine.device
+        npad = self._engine.np
+        self._raw = torch.zeros((16 + 2 * npad,), dtype=torch.uint8, device=dev_t)
+        self._buf = {
+            "reward": self._raw[0:8].view(torch.float64),
+            "steps": self._raw[8:12].view(torch.int32),
+            "terminated": self._raw[12:13],
+            "truncated": self._raw[13:14],
+            "dgoals": self._raw[14:15].view(torch.int8),
+            "pos": self._raw[16:].view(torch.int8).view(1, npad, 2),
+        }
+        self._pid = torch.zeros((1,), dtype=torch.int32, device=dev_t)
+        self._acts = torch.arange(4, dtype=torch.uint8, device=dev_t)  # action a = the 1-element view [a : a + 1]
         self._obs_storage, self._obs = self._engine.alloc_obs(1)
         self.obs_shape = self._engine.obs_shape
+        self._raw_host = torch.zeros_like(self._raw, device="cpu").pin_memory()
+        self._obs_host = torch.zeros(self.obs_shape, dtype=torch.float32).pin_memory()
 
     # ------------------------------------------------------------------
-    def _state_from_device(self):
-        n = self._current_puzzle.num_movables
-        arr = self._buf["pos"][0, :n].cpu().tolist()
-        return tuple((int(x), int(y)) for x, y in arr)
+    def _read_back(self):
+        """Observation + scalars + positions to pinned host memory: two async copies, one synchronisation."""
+        self._obs_host.copy_(self._obs[0], non_blocking=True)
+        self._raw_host.copy_(self._raw, non_blocking=True)
+        torch.cuda.current_stream(self._engine.device).synchronize()
+        return self._obs_host.numpy().copy(), self._raw_host.numpy()
 
     def core_reset(self, seed: Optional[int]) -> np.ndarray:
         if seed is not None:
@@ -90,22 +105,25 @@ class SingleEnvCore:
         self._current_state = self._current_puzzle.initial_state
         self._current_achieved_goals = self._current_puzzle.count_achieved_goals(self._current_state)
         self._steps = 0
-        return self._obs[0].cpu().numpy()
+        return self._read_back()[0]
 
     def core_step(self, action: int):
         """Returns (observation, reward: float, terminated: bool, truncated: bool)."""
         if self._current_state is None:
             raise RuntimeError("reset() must be called before step() can be called.")
         b = self._buf
-        self._act.fill_(int(action))
-        self._engine.step_render(self._pid, self._act, b["pos"], b["steps"], b["reward"], b["dgoals"],
-                                 b["terminated"], b["truncated"], self._obs_storage)
-        observation = self._obs[0].cpu().numpy()  # synchronises the stream
+        act = self._acts[int(action):int(action) + 1]
+        # the observation buffer is this environment's own and always current: incremental redraw
+        self._engine.step_render_delta(self._pid, act, b["pos"], b["steps"], b["reward"], b["dgoals"],
+                                       b["terminated"], b["truncated"], self._obs_storage)
+        observation, raw = self._read_back()
         self._steps += 1
-        self._current_state = self._state_from_device()
-        reward = float(b["reward"].cpu()[0])
-        terminated = bool(b["terminated"].cpu()[0])
-        truncated = bool(b["truncated"].cpu()[0])
+        n = self._current_puzzle.num_movables
+        xy = raw[16:16 + 2 * n].view(np.int8)
+        self._current_state = tuple((int(xy[2 * j]), int(xy[2 * j + 1])) for j in range(n))
+        reward = float(raw[0:8].view(np.float64)[0])
+        terminated = bool(raw[12])
+        truncated = bool(raw[13])
         return observation, reward, terminated, truncated
 
     def core_render_u8(self) -> np.ndarray:
