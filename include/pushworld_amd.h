@@ -14,7 +14,8 @@
  *     exception crosses the ABI; pw_last_error() returns a thread-local message.
  *   - "device pointers" are caller-owned HBM buffers (e.g. tensor.data_ptr());
  *     `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
- *     are asynchronous on that stream; the engine never allocates per call.
+ *     are asynchronous on that stream; the engine never allocates per call (one exception:
+ *     pw_step_render_delta allocates a 4 B / environment scratch on first use or batch growth).
  *   - calls on one engine must be externally serialised (like the reference
  *     objects, puzzle.py:310 / pushworld_puzzle.h:178-180, which are not
  *     re-entrant); different engines are independent.
