@@ -43,6 +43,10 @@ struct PwEngine {
   int64_t obs_bytes;
   size_t render_lds;
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
+  bool page_f32;           // float32, pixels_per_cell 3, border_width 1: page-ordered / delta kernels over a second,
+                           // frame-layout zone table (the generic LDS kernel keeps its own layout)
+  uint16_t* d_estat_page;
+  uint32_t* d_estat_page_off;
   int step_kernel;         // 0 group (default), 1 wavefront per env, 2 lane per env (PUSHWORLD_AMD_STEP)
   bool force_fused;        // PUSHWORLD_AMD_FUSED=1: pw_step_render always uses the single fused launch
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
@@ -1237,6 +1241,9 @@ struct PageEnv {
   uint32_t env;
 };
 
+// ES = bytes per channel value (1: uint8, 4: float32).  Offsets inside an image are kept in BYTES (`lo`);
+// entries are addressed in channel units: entry q covers channels [9 q + shift, 9 q + shift + 9).
+template <int ES>
 __device__ __forceinline__ PageEnv page_env(const RenderArgs& a, int pid, uint32_t env, int lo) {
   PageEnv pe;
   pe.h = a.hdrs + pid;
@@ -1252,8 +1259,8 @@ __device__ __forceinline__ PageEnv page_env(const RenderArgs& a, int pid, uint32
   pe.shift_bytes = 3 * (pady * a.pad_w * 3 + padx - 3 * pe.c0);
   pe.n_entries = 3 * pe.H * a.pad_w;
   pe.lo = lo;
-  // entry holding byte lo is floor((lo - shift) / 9); two entries of margin (floor division)
-  const int t = lo - pe.shift_bytes;
+  // entry holding the first channel of the page is floor((lo / ES - shift) / 9); two entries of margin
+  const int t = (lo >= 0 ? lo / ES : -((-lo) / ES)) - pe.shift_bytes;
   pe.q_lo = (t >= 0 ? t / 9 : -((-t + 8) / 9)) - 2;
   pe.env = env;
   return pe;
@@ -1272,9 +1279,10 @@ __device__ __forceinline__ int page_load_xy(const RenderArgs& a, uint32_t env, i
 }
 
 // `any` = some movable's rows meet the page
+template <int ES>
 __device__ __forceinline__ bool page_prefilter(const RenderArgs& a, const PageEnv& pe, int lane, int xy) {
-  const int row_bytes = 9 * a.pad_w;  // one image row
-  const int lo = pe.lo, hi = pe.lo + 4096;
+  const int row_bytes = 9 * a.pad_w;  // one image row, in channels
+  const int lo = pe.lo / ES, hi = lo + 4096 / ES;  // (exact: lo is a multiple of 16, also when negative)
   bool hit = false;
   if (lane < pe.N) {
     const int y = static_cast<int8_t>((xy >> 8) & 0xff);
@@ -1284,9 +1292,10 @@ __device__ __forceinline__ bool page_prefilter(const RenderArgs& a, const PageEn
   return __ballot(hit) != 0ull;
 }
 
+template <int ES>
 __device__ __forceinline__ void page_mark(const RenderArgs& a, const PageEnv& pe, int lane, int xy, uint32_t* win, uint32_t* dirty) {
-  const int row_bytes = 9 * a.pad_w;  // one image row
-  const int lo = pe.lo, hi = pe.lo + 4096;
+  const int row_bytes = 9 * a.pad_w;  // one image row, in channels
+  const int lo = pe.lo / ES, hi = lo + 4096 / ES;
   const uint32_t* mcells = reinterpret_cast<const uint32_t*>(a.blob + pe.h->base + pe.h->off_mcells);
   for (int m0 = 0; m0 < pe.n_mcells; m0 += PW_WAVE) {
     const int m = m0 + lane;
@@ -1309,15 +1318,45 @@ __device__ __forceinline__ void page_mark(const RenderArgs& a, const PageEnv& pe
       if (b0 + 9 <= lo || b0 >= hi) continue;
       const uint32_t e = pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_entry_goal_bits(pe.estat[q]));
       atomicMax(&win[q - pe.q_lo], (static_cast<uint32_t>(obj + 1) << 12) | e);
-      const int cl = max(b0 - lo, 0) >> 4, ch = min(b0 + 8 - lo, 4095) >> 4;
-      atomicOr(&dirty[cl >> 5], 1u << (cl & 31));
-      atomicOr(&dirty[ch >> 5], 1u << (ch & 31));
+      const int cl = (max(b0 - lo, 0) * ES) >> 4, ch = (min(b0 + 8 - lo, 4096 / ES - 1) * ES) >> 4;
+      if (ES == 1) {  // 9 bytes touch at most two 16-byte chunks
+        atomicOr(&dirty[cl >> 5], 1u << (cl & 31));
+        atomicOr(&dirty[ch >> 5], 1u << (ch & 31));
+      } else {        // 36 bytes: up to four
+        for (int cc = cl; cc <= ch; cc++) atomicOr(&dirty[cc >> 5], 1u << (cc & 31));
+      }
     }
   }
 }
 
 // the 16 bytes of chunk c (inside the environment's image) from the page's entry window + static table
 typedef unsigned int pw_u32x4 __attribute__((ext_vector_type(4)));
+// float32: chunk c = channels 4 c .. 4 c + 3 of the environment's image = parts of at most two entries;
+// palf = the 16 x 4 table of exact uint8 / 255 values (env_utils.py:65-72)
+__device__ __forceinline__ pw_u32x4 page_chunk_f32(const PageEnv& pe, int c, const uint32_t* win, const float* palf) {
+  const int bias_q = (pe.shift_bytes > 0 ? pe.shift_bytes / 9 : 0) + 2;
+  const unsigned o3 = static_cast<unsigned>(c * 4 - pe.shift_bytes + 9 * bias_q);
+  const unsigned qb = o3 / 9u;
+  const int r0 = static_cast<int>(o3 - qb * 9u);
+  const int q0 = static_cast<int>(qb) - bias_q;
+  const uint32_t w0 = win[q0 - pe.q_lo], w1 = win[q0 + 1 - pe.q_lo];
+  const uint32_t e0 = w0 ? (w0 & 0xFFFu) : ((static_cast<unsigned>(q0) < static_cast<unsigned>(pe.n_entries)) ? pe.estat[q0] : 0u);
+  const uint32_t e1 = w1 ? (w1 & 0xFFFu) : ((static_cast<unsigned>(q0 + 1) < static_cast<unsigned>(pe.n_entries)) ? pe.estat[q0 + 1] : 0u);
+  union {
+    float f[4];
+    pw_u32x4 v;
+  } out;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int r = r0 + k;
+    const uint32_t e = r < 9 ? e0 : e1;
+    const int rr = r < 9 ? r : r - 9;
+    const int px = rr >= 6 ? 2 : (rr >= 3 ? 1 : 0);
+    out.f[k] = palf[((e >> (4 * px)) & 15u) * 4 + (rr - 3 * px)];
+  }
+  return out.v;
+}
+
 __device__ __forceinline__ pw_u32x4 page_chunk(const PageEnv& pe, int c, const uint32_t* win, const uint32_t* pal) {
   const int bias_q = (pe.shift_bytes > 0 ? pe.shift_bytes / 9 : 0) + 2;
   const unsigned o3 = static_cast<unsigned>(c * 16 - pe.shift_bytes + 9 * bias_q);
@@ -1351,9 +1390,12 @@ __device__ __forceinline__ pw_u32x4 page_chunk(const PageEnv& pe, int c, const u
                   __builtin_amdgcn_alignbyte(s3, s2, bs), __builtin_amdgcn_alignbyte(s4, s3, bs)};
 }
 
+#define PAGE_CHUNK(...) (ES == 1 ? page_chunk(__VA_ARGS__, pal) : page_chunk_f32(__VA_ARGS__, reinterpret_cast<const float*>(pal)))
+template <typename T>
 __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyArgs ca) {
   typedef pw_u32x4 u32x4;
-  __shared__ uint32_t pal[16];
+  constexpr int ES = static_cast<int>(sizeof(T));
+  __shared__ uint32_t pal[ES == 1 ? 16 : 64];  // uint8: packed RGB; float32: 16 x 4 float bit patterns
   __shared__ uint32_t dirty[8];
   __shared__ __align__(16) uint32_t win0[PW_PAGE_ENTRIES];
   __shared__ __align__(16) uint32_t win1[PW_PAGE_ENTRIES];
@@ -1383,21 +1425,25 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
     u32x4 v1 = *reinterpret_cast<const u32x4*>(src + 1024);
     u32x4 v2 = *reinterpret_cast<const u32x4*>(src + 2048);
     u32x4 v3 = *reinterpret_cast<const u32x4*>(src + 3072);
-    const PageEnv pe = page_env(a, pid0, env0, c_first * 16);
+    const PageEnv pe = page_env<ES>(a, pid0, env0, c_first * 16);
     const int xy = xy0;
-    if (page_prefilter(a, pe, lane, xy)) {  // ~40 % of the pages: some movable's rows cross this page
-      if (lane < 16) pal[lane] = a.pal_rgb[lane];
+    if (page_prefilter<ES>(a, pe, lane, xy)) {  // ~40 % of the pages: some movable's rows cross this page
+      if (ES == 1) {
+        if (lane < 16) pal[lane] = a.pal_rgb[lane];
+      } else {
+        pal[lane] = __float_as_uint(a.pal_f32[lane >> 2][lane & 3]);
+      }
       if (lane < 8) dirty[lane] = 0;
       for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
-      page_mark(a, pe, lane, xy, win0, dirty);
+      page_mark<ES>(a, pe, lane, xy, win0, dirty);
       __syncthreads();
       if (dirty[0] | dirty[1] | dirty[2] | dirty[3] | dirty[4] | dirty[5] | dirty[6] | dirty[7]) {
         const int bit = lane & 31, wsel = lane >> 5;
-        if ((dirty[0 + wsel] >> bit) & 1u) v0 = page_chunk(pe, c_first + lane, win0, pal);
-        if ((dirty[2 + wsel] >> bit) & 1u) v1 = page_chunk(pe, c_first + lane + 64, win0, pal);
-        if ((dirty[4 + wsel] >> bit) & 1u) v2 = page_chunk(pe, c_first + lane + 128, win0, pal);
-        if ((dirty[6 + wsel] >> bit) & 1u) v3 = page_chunk(pe, c_first + lane + 192, win0, pal);
+        if ((dirty[0 + wsel] >> bit) & 1u) v0 = PAGE_CHUNK(pe, c_first + lane, win0);
+        if ((dirty[2 + wsel] >> bit) & 1u) v1 = PAGE_CHUNK(pe, c_first + lane + 64, win0);
+        if ((dirty[4 + wsel] >> bit) & 1u) v2 = PAGE_CHUNK(pe, c_first + lane + 128, win0);
+        if ((dirty[6 + wsel] >> bit) & 1u) v3 = PAGE_CHUNK(pe, c_first + lane + 192, win0);
       }
     }
     __builtin_nontemporal_store(v0, reinterpret_cast<u32x4*>(dst));
@@ -1428,26 +1474,30 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
     v[k] = u32x4{0u, 0u, 0u, 0u};
     if (ok[k]) v[k] = *reinterpret_cast<const u32x4*>((second[k] ? src1 : src0) + lc * 16);
   }
-  const PageEnv pe0 = page_env(a, pid0, env0, c_first * 16);
-  const PageEnv pe1 = page_env(a, pid1, env0 + 1u, -split * 16);
-  const bool hit0 = page_prefilter(a, pe0, lane, xy0);
-  const bool hit1 = has_second && page_prefilter(a, pe1, lane, xy1);
+  const PageEnv pe0 = page_env<ES>(a, pid0, env0, c_first * 16);
+  const PageEnv pe1 = page_env<ES>(a, pid1, env0 + 1u, -split * 16);
+  const bool hit0 = page_prefilter<ES>(a, pe0, lane, xy0);
+  const bool hit1 = has_second && page_prefilter<ES>(a, pe1, lane, xy1);
   if (hit0 || hit1) {
-    if (lane < 16) pal[lane] = a.pal_rgb[lane];
+    if (ES == 1) {
+        if (lane < 16) pal[lane] = a.pal_rgb[lane];
+      } else {
+        pal[lane] = __float_as_uint(a.pal_f32[lane >> 2][lane & 3]);
+      }
     if (lane < 8) dirty[lane] = 0;
     for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) {
       reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
       reinterpret_cast<uint4*>(win1)[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
-    if (hit0) page_mark(a, pe0, lane, xy0, win0, dirty);
-    if (hit1) page_mark(a, pe1, lane, xy1, win1, dirty);
+    if (hit0) page_mark<ES>(a, pe0, lane, xy0, win0, dirty);
+    if (hit1) page_mark<ES>(a, pe1, lane, xy1, win1, dirty);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int lc = lane + 64 * k;
       if (ok[k] && ((dirty[lc >> 5] >> (lc & 31)) & 1u))
-        v[k] = second[k] ? page_chunk(pe1, lc - split, win1, pal) : page_chunk(pe0, c_first + lc, win0, pal);
+        v[k] = second[k] ? PAGE_CHUNK(pe1, lc - split, win1) : PAGE_CHUNK(pe0, c_first + lc, win0);
     }
   }
 #pragma unroll
@@ -1464,9 +1514,11 @@ __global__ __launch_bounds__(64) void pw_render_page_kernel(RenderArgs a, CopyAr
 // window over ALL movables that reach into the segment), 4 KiB at a time.  Environments that were
 // reset carry the full interval and are redrawn completely.
 // ------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyArgs ca, const uint32_t* dirty_rows) {
   typedef pw_u32x4 u32x4;
-  __shared__ uint32_t pal[16];
+  constexpr int ES = static_cast<int>(sizeof(T));
+  __shared__ uint32_t pal[ES == 1 ? 16 : 64];
   __shared__ uint32_t dirty[8];
   __shared__ __align__(16) uint32_t win0[PW_PAGE_ENTRIES];
   const int lane = threadIdx.x;
@@ -1479,7 +1531,7 @@ __global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyA
   if (yhi_raw <= ylo) return;  // nothing moved: the buffer is already right
   const int H = static_cast<int>(d >> 16);  // from the record: the chunk range needs no header load
   const int pady = (a.pad_h - H) * 3 / 2;
-  const int row_bytes = 9 * a.pad_w;
+  const int row_bytes = 9 * a.pad_w * ES;
   const int yhi = min(yhi_raw, H);
   // a reset environment (interval 0 .. PW_MAX_DIM) may have changed puzzle: the whole frame, padding included
   const bool whole = yhi_raw >= PW_MAX_DIM;
@@ -1488,9 +1540,13 @@ __global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyA
                          : min(((pady + 3 * yhi) * row_bytes + 15) >> 4, static_cast<int>(ca.n_chunks));
   uint8_t* dst = a.obs + static_cast<int64_t>(env) * a.env_stride;
   const uint8_t* src = ca.simg + static_cast<int64_t>(pid) * ca.simg_stride;
-  if (lane < 16) pal[lane] = a.pal_rgb[lane];
+  if (ES == 1) {
+    if (lane < 16) pal[lane] = a.pal_rgb[lane];
+  } else {
+    pal[lane] = __float_as_uint(a.pal_f32[lane >> 2][lane & 3]);
+  }
   for (int c0 = c_lo; c0 < c_hi; c0 += 256) {
-    const PageEnv pe = page_env(a, pid, env, c0 * 16);
+    const PageEnv pe = page_env<ES>(a, pid, env, c0 * 16);
     u32x4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1499,16 +1555,16 @@ __global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyA
       if (c < c_hi) v[k] = *reinterpret_cast<const u32x4*>(src + static_cast<int64_t>(c) * 16);
     }
     __syncthreads();  // the previous segment's window is no longer read
-    if (page_prefilter(a, pe, lane, xy)) {
+    if (page_prefilter<ES>(a, pe, lane, xy)) {
       if (lane < 8) dirty[lane] = 0;
       for (int i = lane; i < PW_PAGE_ENTRIES / 4; i += PW_WAVE) reinterpret_cast<uint4*>(win0)[i] = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
-      page_mark(a, pe, lane, xy, win0, dirty);
+      page_mark<ES>(a, pe, lane, xy, win0, dirty);
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int lc = lane + 64 * k;
-        if (c0 + lc < c_hi && ((dirty[lc >> 5] >> (lc & 31)) & 1u)) v[k] = page_chunk(pe, c0 + lc, win0, pal);
+        if (c0 + lc < c_hi && ((dirty[lc >> 5] >> (lc & 31)) & 1u)) v[k] = PAGE_CHUNK(pe, c0 + lc, win0);
       }
     }
 #pragma unroll
@@ -1518,6 +1574,8 @@ __global__ __launch_bounds__(64) void pw_render_delta_kernel(RenderArgs a, CopyA
     }
   }
 }
+
+#undef PAGE_CHUNK
 
 // Generic path: any pixels_per_cell / border_width, uint8 or float32 elements.
 // One thread produces 16 bytes (16 uint8 or 4 float32 channel values) per iteration.
@@ -1729,6 +1787,9 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
     return pw_fail(PW_ELIMIT, "observation larger than 1 GiB");
   }
   e->fast_u8_ppc3 = cfg->obs_dtype == PW_OBS_U8 && cfg->pixels_per_cell == 3 && cfg->border_width == 1;
+  e->page_f32 = cfg->obs_dtype == PW_OBS_F32 && cfg->pixels_per_cell == 3 && cfg->border_width == 1;
+  e->d_estat_page = nullptr;
+  e->d_estat_page_off = nullptr;
   e->d_estat = nullptr;
   e->d_estat_off = nullptr;
   {
@@ -1740,31 +1801,35 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   // Static zone-colour tables (walls, agent walls, background, goal outlines) of every puzzle in
   // the layout the render kernel of this engine streams from: row stride pad_w with the puzzle
   // shifted by c0 virtual columns for the 3-pixel fast path, row stride W otherwise.
-  std::vector<uint16_t> estat;
-  std::vector<uint32_t> estat_off(s->count);
+  std::vector<uint16_t> estat, estat_page;
+  std::vector<uint32_t> estat_off(s->count), estat_page_off(s->count);
   size_t max_e_bytes = 0;
-  for (int p = 0; p < s->count; p++) {
-    const PwPuzzleHeader& h = s->headers[p];
-    const int W = h.W, H = h.H;
-    const int estride = e->fast_u8_ppc3 ? e->pad_w : W;
-    const int c0 = e->fast_u8_ppc3 ? ((e->pad_w - W) * 3 / 2 + 2) / 3 : 0;
-    const uint32_t* codes = reinterpret_cast<const uint32_t*>(s->blob.data() + h.base + h.off_static);
-    const size_t n_entries = static_cast<size_t>(3) * H * estride;
-    const size_t e_bytes = ((2 * (n_entries + 3) + 15) >> 4) << 4;
-    max_e_bytes = std::max(max_e_bytes, e_bytes);
-    estat_off[p] = static_cast<uint32_t>(estat.size() * 2);
-    const size_t first = estat.size();
-    estat.resize(first + e_bytes / 2, 0);
-    for (int cy = 0; cy < H; cy++)
-      for (int cx = 0; cx < W; cx++) {
-        const uint32_t code = codes[cy * W + cx];
-        const uint32_t kind = (code >> PW_CODE_KIND_SHIFT) & 0xfu;
-        const uint32_t om = code & 0xffu, gm = code >> PW_CODE_GOAL_SHIFT;
-        for (int zy = 0; zy < 3; zy++)
-          estat[first + static_cast<size_t>(3 * cy + zy) * estride + cx + c0] =
-              static_cast<uint16_t>(pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_zone_border_bits(gm, zy)));
-      }
-  }
+  auto build_tables = [&](bool frame_layout, std::vector<uint16_t>& tab, std::vector<uint32_t>& off, size_t* max_bytes) {
+    for (int p = 0; p < s->count; p++) {
+      const PwPuzzleHeader& h = s->headers[p];
+      const int W = h.W, H = h.H;
+      const int estride = frame_layout ? e->pad_w : W;
+      const int c0 = frame_layout ? ((e->pad_w - W) * 3 / 2 + 2) / 3 : 0;
+      const uint32_t* codes = reinterpret_cast<const uint32_t*>(s->blob.data() + h.base + h.off_static);
+      const size_t n_entries = static_cast<size_t>(3) * H * estride;
+      const size_t e_bytes = ((2 * (n_entries + 3) + 15) >> 4) << 4;
+      if (max_bytes) *max_bytes = std::max(*max_bytes, e_bytes);
+      off[p] = static_cast<uint32_t>(tab.size() * 2);
+      const size_t first = tab.size();
+      tab.resize(first + e_bytes / 2, 0);
+      for (int cy = 0; cy < H; cy++)
+        for (int cx = 0; cx < W; cx++) {
+          const uint32_t code = codes[cy * W + cx];
+          const uint32_t kind = (code >> PW_CODE_KIND_SHIFT) & 0xfu;
+          const uint32_t om = code & 0xffu, gm = code >> PW_CODE_GOAL_SHIFT;
+          for (int zy = 0; zy < 3; zy++)
+            tab[first + static_cast<size_t>(3 * cy + zy) * estride + cx + c0] =
+                static_cast<uint16_t>(pw_zone_entry(kind, pw_zone_border_bits(om, zy), pw_zone_border_bits(gm, zy)));
+        }
+    }
+  };
+  build_tables(e->fast_u8_ppc3, estat, estat_off, &max_e_bytes);
+  if (e->page_f32) build_tables(true, estat_page, estat_page_off, nullptr);
   e->render_lds = 16 + max_e_bytes + 64 + 64 + 16 + 256;  // guard, E, spos, pal, flag, float palette
   for (int i = 0; i < 16; i++) {
     e->pal_rgb[i] = 0;
@@ -1785,6 +1850,14 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   if (err == hipSuccess) err = hipMemcpy(e->d_estat, estat.data(), estat.size() * 2, hipMemcpyHostToDevice);
   if (err == hipSuccess)
     err = hipMemcpy(e->d_estat_off, estat_off.data(), estat_off.size() * 4, hipMemcpyHostToDevice);
+  if (e->page_f32) {
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_estat_page), estat_page.size() * 2);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_estat_page_off), estat_page_off.size() * 4);
+    if (err == hipSuccess)
+      err = hipMemcpy(e->d_estat_page, estat_page.data(), estat_page.size() * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess)
+      err = hipMemcpy(e->d_estat_page_off, estat_page_off.data(), estat_page_off.size() * 4, hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_render_u8_ppc3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->render_lds));
@@ -1807,7 +1880,7 @@ int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine**
   // The delta kernel reads only the rows a step changed, so for it the images may live in HBM (<= 4 GB).
   const int64_t simg_total = static_cast<int64_t>(s->count) * e->simg_stride;
   e->simg_cached = !want_lds && simg_total <= (int64_t(64) << 20);
-  const bool want_page = e->fast_u8_ppc3 && simg_total <= (int64_t(4) << 30);
+  const bool want_page = (e->fast_u8_ppc3 || e->page_f32) && simg_total <= (int64_t(4) << 30);
   if (err == hipSuccess && want_page) {
     int32_t* d_ids = nullptr;
     int8_t* d_pos = nullptr;
@@ -1848,6 +1921,8 @@ void pw_engine_destroy(PwEngine* e) {
   if (!e) return;
   if (e->d_estat) (void)hipFree(e->d_estat);
   if (e->d_estat_off) (void)hipFree(e->d_estat_off);
+  if (e->d_estat_page) (void)hipFree(e->d_estat_page);
+  if (e->d_estat_page_off) (void)hipFree(e->d_estat_page_off);
   if (e->d_simg) (void)hipFree(e->d_simg);
   if (e->d_dirty) (void)hipFree(e->d_dirty);
   delete e;
@@ -1869,6 +1944,8 @@ int pw_engine_render_kernel(const PwEngine* e, char* buf, int cap) {
   if (e->fast_u8_ppc3) {
     if (!e->d_simg || !e->simg_cached) name = "pw_render_u8_ppc3_kernel";
     else name = "pw_render_page_kernel";
+  } else if (e->page_f32 && e->d_simg && e->simg_cached) {
+    name = "pw_render_page_kernel";
   }
   const int n = static_cast<int>(strlen(name));
   if (buf && cap > 0) {
@@ -1938,7 +2015,15 @@ static void launch_render(PwEngine* e, const RenderArgs& ra, int32_t batch, hipS
     ca.n_chunks = static_cast<uint32_t>((e->obs_bytes + 15) / 16);
     ca.inv_cpe = 1.0f / static_cast<float>(ca.chunks_per_env);
     const uint64_t total = static_cast<uint64_t>(batch) * ca.chunks_per_env;
-    hipLaunchKernelGGL(pw_render_page_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(64), 0, st, ra, ca);
+    const dim3 pgrid(static_cast<unsigned>((total + 255) / 256));
+    if (e->page_f32) {
+      RenderArgs rp = ra;  // the page kernels index the frame-layout zone table
+      rp.estat = e->d_estat_page;
+      rp.estat_off = e->d_estat_page_off;
+      hipLaunchKernelGGL(pw_render_page_kernel<float>, pgrid, dim3(64), 0, st, rp, ca);
+    } else {
+      hipLaunchKernelGGL(pw_render_page_kernel<uint8_t>, pgrid, dim3(64), 0, st, ra, ca);
+    }
     return;
   }
   const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
@@ -2068,6 +2153,9 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
   if (!e) return pw_fail(PW_EINVAL, "null engine");
   // uint8 / ppc 3 engines patch from their static images, every other engine redraws the changed rows with
   // the generic LDS kernel; both need the group step kernel (it reports the rows).  Otherwise: full render.
+  // float32 / ppc 3 also has static images, but its changed rows are 4x the bytes: one wavefront walking them
+  // 4 KiB at a time (0.29 ms) loses to the 256-thread generic redraw (0.27 ms), so only uint8 patches from images
+  const bool page_path = e->fast_u8_ppc3 && e->d_simg;
   if ((e->fast_u8_ppc3 && !e->d_simg) || e->step_kernel != 0 || e->force_fused)
     return pw_step_render(e, puzzle_id, actions, pos, steps, reward, dgoals, terminated, truncated, obs, env_stride_bytes,
                           batch, flags, stream);
@@ -2095,7 +2183,7 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
   r.term_hist = nullptr;
   r.trunc_hist = nullptr;
   launch_group(e, r, batch, st);
-  if (!e->fast_u8_ppc3) {
+  if (!page_path) {
     ra.dirty_rows = e->d_dirty;
     const dim3 grid(static_cast<unsigned>(batch)), block(PW_RENDER_THREADS);
     if (e->cfg.obs_dtype == PW_OBS_U8)
@@ -2113,7 +2201,7 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
   ca.chunks_per_env = static_cast<uint32_t>(env_stride_bytes / 16);
   ca.n_chunks = static_cast<uint32_t>((e->obs_bytes + 15) / 16);
   ca.inv_cpe = 1.0f / static_cast<float>(ca.chunks_per_env);
-  hipLaunchKernelGGL(pw_render_delta_kernel, dim3(static_cast<unsigned>(batch)), dim3(64), 0, st, ra, ca, e->d_dirty);
+  hipLaunchKernelGGL(pw_render_delta_kernel<uint8_t>, dim3(static_cast<unsigned>(batch)), dim3(64), 0, st, ra, ca, e->d_dirty);
   return check_launch("pw_step_render_delta");
 }
 

@@ -193,8 +193,9 @@ def test_full_small_images(golden, puzzles, torch_mod):
         assert (img == want).all(), (key, np.argwhere(img != want)[:5])
 
 
+@pytest.mark.parametrize("obs_kind", ["uint8", "float32"])
 @pytest.mark.parametrize("path", ["page"])
-def test_page_render_matches_lds_kernel(golden, torch_mod, path, monkeypatch):
+def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monkeypatch):
     """The page-ordered render kernel (default for uint8 / ppc 3: static-image copy + LDS entry window)
     and the per-environment LDS kernel (PUSHWORLD_AMD_RENDER=lds) produce byte-identical observations
     on a mixed Level-1 batch along random walks and on overlapping (illegal) states."""
@@ -209,12 +210,13 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, monkeypatch):
 
     def make():
         return VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, pixels_per_cell=3,
-                            border_width=1, observation="uint8", device=0, autoreset=True)
+                            border_width=1, observation=obs_kind, device=0, autoreset=True)
 
     monkeypatch.setenv("PUSHWORLD_AMD_RENDER", "lds")
     ref = make()
     monkeypatch.setenv("PUSHWORLD_AMD_RENDER", path)
     alt = make()
+    assert ref.engine.render_kernel != "pw_render_page_kernel" and alt.engine.render_kernel == "pw_render_page_kernel"
     o_ref, o_alt = ref.reset(), alt.reset()
     assert torch.equal(o_ref, o_alt)
     gen = torch.Generator(device=ref.device)
