@@ -225,12 +225,12 @@ class PushWorldPuzzle:
         eng = self._engine()
         b = self._state_bufs(eng)
         self._upload(eng, self._initial_state)
-        acts = torch.tensor(plan, dtype=torch.uint8).to(eng.device)
-        term = torch.zeros((len(plan),), dtype=torch.uint8, device=eng.device)
-        for t in range(len(plan)):
-            eng.step(b["pid"], acts[t : t + 1], b["pos"], b["steps"], b["reward"], b["dgoals"], term[t : t + 1],
-                     b["truncated"])
-        hist = term.cpu().numpy()
+        # ONE launch for the whole plan: pw_rollout with the per-step terminated flags as history
+        acts = torch.tensor(plan, dtype=torch.uint8).view(len(plan), 1).to(eng.device)
+        term = torch.zeros((len(plan), 1), dtype=torch.uint8, device=eng.device)
+        eng.rollout(b["pid"], acts, b["pos"], b["steps"], b["reward"], b["dgoals"], b["terminated"], b["truncated"],
+                    None, term, None)
+        hist = term.cpu().numpy().reshape(-1)
         return bool(hist[-1] == 1 and not hist[:-1].any())
 
     def expand4(self, states):
