@@ -194,7 +194,8 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
 int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs,
               int64_t env_stride_bytes, int32_t batch, void* stream);
 
-/* pw_step followed by pw_render of the new state on the same stream. */
+/* pw_step followed by pw_render of the new state on the same stream (PUSHWORLD_AMD_FUSED=1 selects a
+ * single launch that runs the step inside the per-environment render workgroups; slower, kept for tests). */
 int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
                    int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
                    uint8_t* truncated, void* obs, int64_t env_stride_bytes, int32_t batch,

@@ -2130,7 +2130,9 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
   rc = fill_render_args(e, puzzle_id, pos, obs, env_stride_bytes, batch, &ra);
   if (rc != PW_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (e->d_simg && e->simg_cached && env_stride_bytes >= 4096 && !e->force_fused) {
+  // two launches (lane-group step kernel, then the render): measured faster than the single fused launch
+  // for every engine -- the wavefront formulation of the step sits on each workgroup's critical path there
+  if (!e->force_fused) {
     RolloutArgs r;
     r.s = sa;
     r.num_steps = 1;
