@@ -180,14 +180,19 @@ class PushWorldVectorEnv(_VectorCore):
         ``(obs [B, H, W, 3], {"puzzle_id": int32 [B]})``."""
         self._pending = False
         obs = self.vec.reset(seed=seed)
-        return self._out(obs), {"puzzle_id": self._out(self.vec.puzzle_id)}
+        return self._out(obs), self._info()
+
+    def _info(self) -> dict:
+        """``puzzle_state``: int8 [B, NP, 2] (x, y) positions, agent first, zero beyond a puzzle's movables
+        (the batched form of the reference's ``info["puzzle_state"]``, gym_env.py:186,226)."""
+        return {"puzzle_id": self._out(self.vec.puzzle_id), "puzzle_state": self._out(self.vec.pos)}
 
     def step_async(self, actions) -> None:
         self._launch(actions)
 
     def step_wait(self):
         obs, reward, terminated, truncated = self._collect()
-        info = {"puzzle_id": self._out(self.vec.puzzle_id)}
+        info = self._info()
         if self.to_numpy:
             return (obs.cpu().numpy(), reward.cpu().numpy(), terminated.cpu().numpy().astype(bool),
                     truncated.cpu().numpy().astype(bool), info)

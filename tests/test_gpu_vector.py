@@ -187,6 +187,10 @@ def test_vector_env_episodes_match_oracle(golden, pool_keys, obs_kind, weighted)
             obs, reward, term, trunc, info = venv.step(a)
         m = model[t + 1]
         assert (info["puzzle_id"].cpu().numpy() == m["pid"]).all(), t
+        states = info["puzzle_state"].cpu().numpy()
+        for b in range(0, B, 7):
+            n = len(m["state"][b])
+            assert [tuple(xy) for xy in states[b, :n].tolist()] == list(m["state"][b]), (t, b)
         assert (reward.cpu().numpy().view(np.uint64) == m["reward"].view(np.uint64)).all(), t
         assert ((term.cpu().numpy() != 0) == m["term"]).all(), t
         assert ((trunc.cpu().numpy() != 0) == m["trunc"]).all(), t
