@@ -140,3 +140,30 @@ def test_incremental_with_large_pool_static_images_in_hbm(golden):
         fo, io = full.step(a), inc.step(a)
         assert torch.equal(fo[0], io[0]), t
         assert torch.equal(full.puzzle_id, inc.puzzle_id) and torch.equal(full.pos, inc.pos), t
+
+
+def test_incremental_full_size_is_a_pure_function_of_the_state():
+    """C3 at the bench's full size (65 536 envs): after 60 incremental steps with autoreset the buffer equals
+    a from-scratch render of the final states, byte for byte, for the whole batch (observation = pure
+    function of (puzzle, state)); a second pass with max_steps 7 forces thousands of resets per step."""
+    import torch
+
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    B = 65536
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    for max_steps, T in ((200, 60), (7, 25)):
+        vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=max_steps, pixels_per_cell=3,
+                           border_width=1, observation="uint8", autoreset=True, incremental=True)
+        vec.reset()
+        g = torch.Generator(device=vec.device).manual_seed(max_steps)
+        for t in range(T):
+            vec.step(torch.randint(0, 4, (B,), dtype=torch.uint8, device=vec.device, generator=g))
+        got = vec._obs_storage.clone()
+        vec.render()  # full render of the same states into the same buffer
+        assert torch.equal(got, vec._obs_storage)
+        del vec, got
+        torch.cuda.empty_cache()
