@@ -235,6 +235,29 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     assert torch.equal(ref.render(), alt.render())
 
 
+def test_page_render_in_slices(golden, torch_mod, monkeypatch):
+    """Buffers beyond 2^31 chunks (32 GiB) are rendered in consecutive slices of whole environments; forced
+    here with 333-environment slices on a 2 048-environment batch (slice bases are not page aligned)."""
+    torch = torch_mod
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    B = 2048
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    kw = dict(puzzle_ids=ids, max_steps=200, pixels_per_cell=3, border_width=1, observation="uint8", device=0, autoreset=True)
+    whole = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, **kw)
+    monkeypatch.setenv("PUSHWORLD_AMD_PAGE_SLICE_ENVS", "333")
+    sliced = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, **kw)
+    assert torch.equal(whole.reset(), sliced.reset())
+    gen = torch.Generator(device=whole.device).manual_seed(12)
+    for t in range(10):
+        a = torch.randint(0, 4, (B,), generator=gen, device=whole.device, dtype=torch.uint8)
+        assert torch.equal(whole.step(a)[0], sliced.step(a)[0]), t
+        assert torch.equal(whole._obs_storage, sliced._obs_storage), t
+
+
 @pytest.mark.parametrize("force_fused", ["1", "0"])
 def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_fused, monkeypatch):
     """pw_step_render on a mixed batch, both schedules (PUSHWORLD_AMD_FUSED=1: ONE launch, step in
