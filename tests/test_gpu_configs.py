@@ -296,3 +296,39 @@ def test_engine_from_packed_set_file(golden, tmp_path):
         for x, y in zip(ra, rb):
             assert torch.equal(x, y), t
     assert torch.equal(a.pos, b.pos)
+
+
+def test_batch_beyond_2_31_chunks():
+    """600 000 environments at the C3 frame: a 34.7 GB observation buffer = 2.17e9 16-byte chunks, more than
+    the page kernel numbers with 32 bits, so the render runs in slices.  Every environment gets the same
+    actions; environments of one puzzle must then equal the corresponding environment of a small batch."""
+    import torch
+
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    pool = [PushWorldPuzzle(p) for p in paths]
+    B = 600_000
+    ids = (np.arange(B, dtype=np.int64) * len(pool)) // B
+    big = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=50, pixels_per_cell=3, border_width=1, observation="uint8",
+                       autoreset=True)
+    small = VecPushWorld(pool, len(pool), puzzle_ids=np.arange(len(pool)), max_steps=50, pixels_per_cell=3, border_width=1,
+                         observation="uint8", autoreset=True)
+    assert big.engine.render_kernel == "pw_render_page_kernel"
+    big.reset()
+    small.reset()
+    probe = torch.as_tensor(np.concatenate([np.arange(0, B, 7919), [B - 1, B - 2, 371_085, 371_086, 371_087]]), device=big.device)
+    rng = np.random.default_rng(0)
+    for t in range(6):
+        a = int(rng.integers(0, 4))
+        ob, _, _, _ = big.step(torch.full((B,), a, dtype=torch.uint8, device=big.device))
+        os_, _, _, _ = small.step(torch.full((len(pool),), a, dtype=torch.uint8, device=small.device))
+        want = os_[big.puzzle_id[probe].long()]
+        assert torch.equal(ob[probe], want), t
+    # the bytes between observations (stride padding) stay untouched (zero) everywhere, also at slice boundaries
+    pad = big._obs_storage[:, big.engine.obs_bytes:]
+    assert int(pad.max()) == 0
+    del big, ob
+    torch.cuda.empty_cache()
