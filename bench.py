@@ -1,26 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the batched PushWorld step engine on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4] [--obs uint8|float32|none]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload = BASELINE.json config C3, per GPU: 65 536 environments over the 68 Level-1
-puzzles (sorted by file name, environments grouped by puzzle), observation frame padded to
-the Level-1 maximum (51 x 42 cells), RGB render ON every step with pixels_per_cell = 3 /
-border_width = 1 / uint8, max_steps = 200 with next-step autoreset, uniform random actions
-pre-generated on the device.  One "step" = one pass of the hot path over the whole batch:
-the step kernel (dynamics, goal, reward, done) + the render kernel (observation).
+``--gpus N`` without a torchrun environment re-executes itself through ``torch.distributed.run`` with N
+ranks (one process per GPU, RCCL over xGMI for the timing barrier and ONE counter reduction); it exits
+non-zero when fewer than N devices are visible instead of quietly measuring one.
 
-One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
-``roofline`` for the dominant kernel (render; HBM bound) measured live with HIP events on the
-launch stream, and ``cpu_baseline`` = the C restatement of the reference algorithm
-(oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample; its ``python_env``
-member is the pure-Python restatement of the reference environment on one core (the reference's own
-Python env cannot travel to the GPU box).
+Workloads (``BASELINE.json`` / SURVEY 8d), per GPU:
+  c3 (default, the headline)  65 536 environments over the 68 Level-1 puzzles (sorted by file name,
+      environments grouped by puzzle), observation frame padded to the Level-1 maximum (51 x 42 cells), RGB
+      render ON every step with pixels_per_cell 3 / border_width 1 / uint8, max_steps 200 with next-step
+      autoreset, uniform random actions pre-generated on the device.
+  c4  65 536 environments per rank of the 524 288-environment full mix: 50 % Level 0 (the 14 000 train
+      puzzles of the 7 families) / 50 % Levels 1-4 (223 puzzles), N_pad 32, frame 54 x 47, action seed
+      100 + rank; state only by default, ``--obs uint8`` adds the ppc-3 render.
+One "step" = one pass of the hot path over the whole batch: the step kernel (dynamics, goal, reward, done)
++ the render kernel (observation).
+
+Timing: ``--windows`` windows of EXACTLY K steps each, every window bracketed by barrier + synchronize on both
+sides, per window the MAX over ranks; ``ms_per_step`` / ``value`` are the MEDIAN window (min / max reported too:
+one 14 ms window is inside the +-3 % spread between observation-buffer allocations).
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects: ``roofline`` for
+the dominant kernel (render; HBM bound), timed live by HIP events the library records around that launch on
+the launch stream (``PW_OPT_PROFILE_RENDER``), and ``cpu_baseline`` = the C restatement of the reference
+algorithm (oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample, with 1 thread and
+with all threads, plus the pure-Python restatement of the reference environment (the reference's own Python
+env cannot travel to the GPU box) on 1 core and on P processes.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +45,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+C4_SEED = 100
 
 
 def level1_paths():
@@ -38,71 +53,159 @@ def level1_paths():
     return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".pwp")]
 
 
-def cpu_baseline(paths, ids_full, max_steps, pad_h, pad_w, ppc, bw, target_seconds=12.0):
-    """The oracle's C port on the host cores, same puzzle mix / action distribution / render
-    settings, bounded sample (about 10-20 s of CPU work)."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw, target_seconds=10.0):
+    """The oracle's C port on the host cores, same puzzle mix / action distribution / render settings, bounded
+    sample: all OpenMP threads (the headline ``value``) and one thread."""
     from oracle import c_oracle
 
-    puzzles = []
-    for p in paths:
-        with open(p) as f:
-            puzzles.append(c_oracle.COraclePuzzle(f.read()))
-    B = 4096
-    stride = len(ids_full) // B
-    ids = np.asarray(ids_full[::stride][:B], dtype=np.int32)
+    B = min(4096, len(ids_full))
+    stride = max(1, len(ids_full) // B)
+    ids_sample = np.asarray(ids_full[::stride][:B], dtype=np.int64)
+    used = np.unique(ids_sample)  # only the puzzles the sample touches are compiled (c4: <= 4096 of 14 223)
+    remap = {int(p): i for i, p in enumerate(used)}
+    puzzles = [c_oracle.COraclePuzzle(texts[int(p)]) for p in used]
+    ids = np.asarray([remap[int(p)] for p in ids_sample], dtype=np.int32)
+    B = len(ids)
     rng = np.random.default_rng(12345)
-    T = 16
-    acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
-    c_oracle.rollout(puzzles, ids, acts, max_steps, True, pad_h, pad_w, ppc, bw)  # warm (threads, caches)
-    t0 = time.perf_counter()
-    _, threads = c_oracle.rollout(puzzles, ids, acts, max_steps, True, pad_h, pad_w, ppc, bw)
-    dt = time.perf_counter() - t0
-    rate = B * T / dt
-    T2 = int(max(8, min(16384, target_seconds * rate / B)))
-    acts = rng.integers(0, 4, size=(T2, B), dtype=np.uint8)
-    t0 = time.perf_counter()
-    c_oracle.rollout(puzzles, ids, acts, max_steps, True, pad_h, pad_w, ppc, bw)
-    dt = time.perf_counter() - t0
+
+    def timed(T, threads):
+        acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
+        t0 = time.perf_counter()
+        _, used_threads = c_oracle.rollout(puzzles, ids, acts, max_steps, render, pad_h, pad_w, ppc, bw, threads=threads)
+        dt = time.perf_counter() - t0
+        return B * T / dt, used_threads, dt
+
+    # an explicit thread count: torch.distributed.run exports OMP_NUM_THREADS=1 to every rank
+    try:
+        all_threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        all_threads = os.cpu_count() or 1
+    out = {}
+    for label, threads, budget in (("all", all_threads, target_seconds), ("one", 1, target_seconds * 0.4)):
+        timed(2, threads)  # warm (thread pool, caches)
+        rate, used_threads, _ = timed(8, threads)
+        T2 = int(max(4, min(16384, budget * rate / B)))
+        rate, used_threads, dt = timed(T2, threads)
+        out[label] = (rate, used_threads, T2, dt)
+    what = f"step + padded uint8 render ppc={ppc}" if render else "step only (no observation)"
+    rate, threads, T2, dt = out["all"]
+    r1, _, T1, dt1 = out["one"]
     return {
-        "value": B * T2 / dt,
+        "value": rate,
         "unit": "env-steps/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{B} envs (same Level-1 mix) x {T2} steps, step + padded uint8 render ppc={ppc}, "
-                  f"OpenMP over envs, {dt:.1f} s",
+        "sample": f"{B} envs (same puzzle mix) x {T2} steps, {what}, OpenMP over envs, {dt:.1f} s",
+        "one_thread": {"value": r1, "cores": 1, "sample": f"{B} envs x {T1} steps, {dt1:.1f} s"},
         "host_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
     }
 
 
-def python_env_baseline(paths, ids_full, max_steps, pad_h, pad_w, ppc, bw, target_seconds=4.0):
+def python_env_baseline(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw, target_seconds=3.0):
     """The pure-Python restatement of the reference environment (oracle/pw_oracle.py: hash-set collision
     tables, per-cell painter, /255 + np.pad -- the closest thing to the reference's own CPU Python env that
-    can travel to this box), one process, same puzzle mix, step + padded observation."""
-    from oracle import pw_oracle
+    can travel to this box): one process, and P independent worker processes."""
+    from oracle import py_bench
 
     rng = np.random.default_rng(777)
-    picks = rng.choice(len(paths), size=4, replace=False)
-    envs = []
-    t_build0 = time.perf_counter()
-    for p in picks:
-        with open(paths[p]) as f:
-            envs.append(pw_oracle.OracleEnv(pw_oracle.OraclePuzzle(f.read()), max_steps))
-    t_build = time.perf_counter() - t_build0
-    for e in envs:
-        e.reset()
-    steps = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < target_seconds:
-        for e in envs:
-            state, _, term, trunc = e.step(int(rng.integers(0, 4)))
-            e.puzzle.observation_u8(state, pad_h, pad_w, ppc, bw)
-            if term or trunc:
-                e.reset()
-            steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
-            "sample": f"4 Level-1 puzzles x {steps // 4} steps, step + padded uint8 render ppc={ppc}, {dt:.1f} s; "
-                      f"collision-table construction of the 4 puzzles took {t_build:.1f} s (not included)"}
+    used = np.unique(np.asarray(ids_full))
+    picks = [int(p) for p in rng.choice(used, size=min(4, len(used)), replace=False)]
+    job = dict(texts=[texts[p] for p in picks], max_steps=max_steps, render=bool(render), pad_h=pad_h, pad_w=pad_w,
+               ppc=ppc, bw=bw, seconds=target_seconds)
+    one = py_bench.run(dict(job, seed=777))
+    procs = min(os.cpu_count() or 1, 128)
+    many = py_bench.run_many(job, procs)
+    what = f"step + padded uint8 render ppc={ppc}" if render else "step only"
+    return {
+        "value": one["steps"] / one["seconds"], "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
+        "sample": f"{len(picks)} puzzles of the mix x {one['steps'] // len(picks)} steps, {what}, {one['seconds']:.1f} s; "
+                  f"collision-table construction took {one['build_seconds']:.1f} s (not included)",
+        "processes": {"value": many["steps_per_s"], "cores": many["processes"],
+                      "sample": f"{many['processes']} worker processes x {target_seconds:.0f} s, same job each"},
+    }
+
+
+# ------------------------------------------------------------------------------------------ workloads
+def build_workload(args, rank, world, device_index):
+    """Returns a dict: vec (VecPushWorld), texts (puzzle index -> text, for the CPU baselines), ids (this rank's
+    puzzle id per environment), label, frame."""
+    from pushworld_amd import _capi
+    from pushworld_amd import benchmark_data as bd
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.sharding import c4_global_puzzle_ids, shard_puzzle_ids
+    from pushworld_amd.vec_env import VecPushWorld
+
+    B = args.envs_per_gpu
+    obs_mode = None if args.obs == "none" else args.obs
+    if args.config == "c3":
+        paths = level1_paths()
+        texts = []
+        for p in paths:
+            with open(p) as f:
+                texts.append(f.read())
+        ids = (np.arange(B, dtype=np.int64) * len(paths)) // B  # grouped by puzzle, ~964 envs each
+        vec = VecPushWorld([PushWorldPuzzle(text=t) for t in texts], B, puzzle_ids=ids, max_steps=args.max_steps,
+                           border_width=args.bw, pixels_per_cell=args.ppc, observation=obs_mode, device=device_index,
+                           autoreset=True)
+        label = "C3: Level-1 mix (68 puzzles, envs grouped by puzzle), step + RGB render every step" if obs_mode else \
+            "C3 puzzles (Level-1 mix), state only"
+        return dict(vec=vec, texts=texts, ids=ids, label=label, n_puzzles=len(texts))
+    # c4: the rank's contiguous shard of the global 524 288-environment assignment, sorted inside the shard
+    l0 = bd.level0_texts()  # 7 families x 2 000 train puzzles
+    texts = list(l0.values())
+    n_l0 = len(texts)
+    for lv in (1, 2, 3, 4):
+        for p in bd.level_paths(lv):
+            with open(p) as f:
+                texts.append(f.read())
+    n_hi = len(texts) - n_l0
+    total = B * world  # 524 288 at the specified 8 x 65 536
+    glob = c4_global_puzzle_ids(total, n_l0, n_hi, C4_SEED)
+    ids = np.sort(shard_puzzle_ids(glob, rank, world))
+    assert len(ids) == B
+    pset = _capi.PuzzleSet([_capi.ParsedPuzzle(t) for t in texts], device_index)
+    vec = VecPushWorld(pset, B, puzzle_ids=ids, max_steps=args.max_steps, border_width=args.bw,
+                       pixels_per_cell=args.ppc, observation=obs_mode, pad_cells=(54, 47), device=device_index,
+                       autoreset=True)
+    label = (f"C4 shard: {n_l0} Level-0 train puzzles (50 % of envs) + {n_hi} Level-1..4 puzzles (50 %), frame 54x47, "
+             + ("step + uint8 ppc-3 render" if obs_mode else "state only"))
+    return dict(vec=vec, texts=texts, ids=ids, label=label, n_puzzles=len(texts))
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` outside torchrun: N ranks through torch.distributed.run, one per device."""
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus and not (args.shared_device and n_dev >= 1):
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} HIP device(s) visible; refusing to measure fewer "
+              f"ranks than asked (use --shared-device only to test the plumbing on one GPU)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PUSHWORLD_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def main():
@@ -110,170 +213,249 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each (median reported)")
+    ap.add_argument("--config", choices=["c3", "c4"], default="c3")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--ppc", type=int, default=3)
     ap.add_argument("--bw", type=int, default=1)
-    ap.add_argument("--obs", choices=["uint8", "float32", "none"], default="uint8")
+    ap.add_argument("--obs", choices=["uint8", "float32", "none"], default=None,
+                    help="default: uint8 for c3, none (state only) for c4")
     ap.add_argument("--max-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused", type=int, default=0,
-                    help="0: pw_step then pw_render (events bracket the render kernel); 1: one pw_step_render call")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="CPU work of the all-threads C-port sample (the other CPU samples scale with it)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the incremental-render / rollout extras")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="plumbing test on a 1-GPU box: all ranks on cuda:0, gloo for the counter reduction "
+                         "(RCCL refuses two ranks on one device)")
+    ap.add_argument("--fused", type=int, default=0, help="1: single fused step+render launch (engine option)")
     args = ap.parse_args()
+    if args.obs is None:
+        args.obs = "uint8" if args.config == "c3" else "none"
+    if args.gpus < 1 or args.steps < 1 or args.windows < 1:
+        raise SystemExit("--gpus, --steps and --windows must be >= 1")
+
+    in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not in_torchrun and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.shared_device:
+        device_index = 0
+    else:
+        if local_rank >= n_dev:
+            raise SystemExit(f"bench.py: rank {rank} (local {local_rank}) has no device: {n_dev} visible, --gpus {args.gpus}")
+        device_index = local_rank
+    torch.cuda.set_device(device_index)
     dist = None
-    # BENCH_FORCE_DIST=1: take the RCCL path even with one rank (smoke test of the N > 1 plumbing on a 1-GPU box)
+    backend = None
+    # BENCH_FORCE_DIST=1: take the collective path even with one rank (smoke test of the N > 1 plumbing)
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
-        import torch.distributed as dist  # RCCL over xGMI; used only for the timing barrier/reduction
+        import torch.distributed as dist  # RCCL over xGMI; used only for the timing barrier / reductions
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.shared_device:
+            backend = "gloo"
+            dist.init_process_group(backend="gloo")
+        else:
+            backend = "nccl"
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+    red_dev = None if backend == "gloo" else torch.device("cuda", device_index)
 
-    from pushworld_amd.puzzle import PushWorldPuzzle
-    from pushworld_amd.vec_env import VecPushWorld
-
-    paths = level1_paths()
-    B = args.envs_per_gpu
-    K, Wm = args.steps, args.warmup
-    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B  # grouped by puzzle, ~964 envs each
-    obs_mode = None if args.obs == "none" else args.obs
-    vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=args.max_steps,
-                       border_width=args.bw, pixels_per_cell=args.ppc, observation=obs_mode,
-                       device=local_rank, autoreset=True)
+    wl = build_workload(args, rank, world, device_index)
+    vec = wl["vec"]
     eng = vec.engine
     dev = vec.device
+    B = args.envs_per_gpu
+    K, Wm, M = args.steps, args.warmup, args.windows
+    obs_mode = None if args.obs == "none" else args.obs
+    if args.fused:
+        eng.set_option("fused_step_render", 1)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)
-    actions = torch.randint(0, 4, (K + Wm, B), generator=gen, device=dev, dtype=torch.uint8)
+    gen.manual_seed((C4_SEED if args.config == "c4" else 1) + rank)
+    n_act = min(Wm + K * M, 4096)  # the action stream is reused cyclically beyond 4 096 steps
+    actions = torch.randint(0, 4, (n_act, B), generator=gen, device=dev, dtype=torch.uint8)
 
     vec.reset()
 
-    def one_step(t, events=None):
-        """One pass of the hot path over the batch.  The HIP events bracket the dominant kernel only
-        (the render launch; with --fused 1 the single fused launch)."""
-        a = actions[t]
+    step_events = []
+
+    def one_step(t, timed=False):
+        """One pass of the hot path over the batch."""
+        a = actions[t % n_act]
         if obs_mode is None:
-            if events is not None:
-                events[0].record()
+            if timed:  # the dominant kernel IS the step kernel; torch's current stream is the launch stream
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             eng.step(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
                      vec.flags)
-        elif args.fused:
-            # ONE launch: wave 0 of each workgroup advances its environment, the workgroup draws it
-            if events is not None:
-                events[0].record()
+            if timed:
+                e1.record()
+                step_events.append((e0, e1))
+        else:
+            # ONE call: step kernel + render launch on the same stream; with PW_OPT_PROFILE_RENDER the library
+            # brackets the render launch with HIP events on that stream
             eng.step_render(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated,
                             vec.truncated, vec._obs_storage, vec.flags)
-        else:
-            # step kernel (tens of microseconds) + render kernel on the same stream
-            eng.step(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
-                     vec.flags)
-            if events is not None:
-                events[0].record()
-            eng.render(vec.puzzle_id, vec.pos, vec._obs_storage)
-        if events is not None:
-            events[1].record()
 
     for t in range(Wm):
         one_step(t)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    if obs_mode is not None:
+        eng.profile_render(K * M)
 
-    torch.cuda.synchronize()
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    windows = []
+    t_next = Wm
+    for _ in range(M):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(K):
+            one_step(t_next + t, timed=True)
+        torch.cuda.synchronize()
+        windows.append(time.perf_counter() - t0)
+        barrier()
+        torch.cuda.synchronize()
+        t_next += K
+
+    # the collectives of the whole job: SUM of the step counters, MAX of every window (a few bytes), and the
+    # per-rank medians gathered for the report
+    from pushworld_amd.sharding import gather_floats, reduce_counters, reduce_max
+
+    own_median = float(np.median(windows))
+    counters, _ = reduce_counters({"env_steps": B * K, "ranks": 1}, own_median, device=red_dev)
+    win_max = reduce_max(windows, device=red_dev)  # per window: the slowest rank
+    per_rank = gather_floats(own_median, device=red_dev)
+    if counters["ranks"] != world:
+        raise SystemExit(f"bench.py: only {counters['ranks']} of {world} ranks reported")
+    elapsed = float(np.median(win_max))
+    total_steps = counters["env_steps"]  # per window, all ranks
+
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(K):
-        one_step(Wm + t, evs[t])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        dist.destroy_process_group()
+    if rank != 0:
+        return
 
-    # the ONLY collective of the whole job: SUM of counters, MAX of the window (a few bytes)
-    from pushworld_amd.sharding import reduce_counters
-
-    counters, elapsed = reduce_counters({"env_steps": B * K}, elapsed, device=dev)
-    total_steps = counters["env_steps"]
-
-    if rank == 0:
-        n_obj = eng.np
-        state_bytes = 2 * n_obj * 2 + 1 + 4 + 4 * 2 + 8 + 1 + 1 + 1  # pos r/w, action, pid, steps r/w, reward, flags
-        out = {
-            "metric": "env-steps/sec",
-            "value": total_steps / elapsed,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": Wm,
-            "ms_per_step": 1000.0 * elapsed / K,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8" if args.obs != "float32" else "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "C3: Level-1 mix (68 puzzles, envs grouped by puzzle), step + RGB render every step",
-                "envs_per_gpu": B,
-                "global_batch": B * world,
-                "frame_cells": [eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc],
-                "pixels_per_cell": args.ppc,
-                "border_width": args.bw,
-                "observation": args.obs,
-                "obs_shape": list(eng.obs_shape),
-                "max_steps": args.max_steps,
-                "autoreset": "next-step",
-                "n_pad": n_obj,
-                "parallelism": f"env-sharded x{world}, no data-path collective",
-            },
+    n_obj = eng.np
+    state_bytes = 2 * n_obj * 2 + 1 + 4 + 4 * 2 + 8 + 1 + 1 + 1  # pos r/w, action, pid, steps r/w, reward, flags
+    out = {
+        "metric": "env-steps/sec",
+        "value": total_steps / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wm,
+        "ms_per_step": 1000.0 * elapsed / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8" if args.obs != "float32" else "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": wl["label"],
+            "config": args.config,
+            "envs_per_gpu": B,
+            "global_batch": B * world,
+            "puzzles": wl["n_puzzles"],
+            "frame_cells": [eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc],
+            "pixels_per_cell": args.ppc,
+            "border_width": args.bw,
+            "observation": args.obs,
+            "obs_shape": list(eng.obs_shape),
+            "max_steps": args.max_steps,
+            "autoreset": "next-step",
+            "n_pad": n_obj,
+            "parallelism": f"env-sharded x{world}, no data-path collective"
+                           + (f" (counters over {backend})" if backend else ""),
+        },
+        "timing": {
+            "windows": M,
+            "steps_per_window": K,
+            "statistic": "median over windows of (max over ranks)",
+            "window_ms_per_step": [1000.0 * w / K for w in win_max],
+            "min_ms_per_step": 1000.0 * min(win_max) / K,
+            "max_ms_per_step": 1000.0 * max(win_max) / K,
+            "per_rank_median_ms_per_step": [1000.0 * w / K for w in per_rank],
+        },
+    }
+    if obs_mode is not None:
+        ms = np.array(eng.profile_read(), dtype=np.float64)
+        assert len(ms) == K * M, (len(ms), K, M)
+        render_s = float(ms.mean()) * 1e-3
+        # render launch: observation write + positions and puzzle id read (DESIGN.md section 4)
+        algo = B * (eng.obs_bytes + 2 * n_obj + 4)
+        achieved = algo / render_s / 1e9
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_render_latest.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    rec = json.load(f)
+                if rec.get("envs") == B and rec.get("obs_bytes") == eng.obs_bytes and \
+                        rec.get("kernel") == eng.render_kernel and not args.fused:
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = "recorded: profiles/pmc_render_latest.json (rocprofv3 --pmc passes of " \
+                                     + str(rec.get("source", "an earlier run")) + "), not measured in this run"
+            except Exception:  # noqa: BLE001
+                traffic = None
+        kname = eng.render_kernel
+        if args.fused:
+            kname = ("pw_render_u8_ppc3_kernel" if kname != "pw_render_generic_kernel" else kname) + " (fused step + render)"
+        out["roofline"] = {
+            "kernel": kname,
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_measured_copy_6290": achieved / 6290.0,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": algo,
+            "avg_launch_ms": float(ms.mean()),
+            "median_launch_ms": float(np.median(ms)),
+            "min_launch_ms": float(ms.min()),
+            "launches_timed": int(len(ms)),
+            "timer": "HIP events recorded by the library around the launch, on the launch stream (rank 0)",
+            "rest_of_step_ms": 1000.0 * elapsed / K - float(ms.mean()),  # step kernel + launch gaps
         }
-        if obs_mode is not None:
-            ms = np.array([a.elapsed_time(b) for a, b in evs])
-            render_s = float(ms.mean()) * 1e-3
-            # render launch: observation write + positions and puzzle id read (DESIGN.md section 4);
-            # the fused launch also carries the step's state traffic
-            algo = B * (eng.obs_bytes + (state_bytes if args.fused else 2 * n_obj + 4))
-            achieved = algo / render_s / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_render_latest.json")
-            if os.path.exists(pmc):
-                try:
-                    with open(pmc) as f:
-                        rec = json.load(f)
-                    if rec.get("envs") == B and rec.get("obs_bytes") == eng.obs_bytes and \
-                            rec.get("kernel") == eng.render_kernel and not args.fused:
-                        traffic = rec.get("hbm_bytes_per_launch")
-                except Exception:  # noqa: BLE001
-                    traffic = None
-            out["roofline"] = {
-                "kernel": ("pw_render_u8_ppc3_kernel (fused step + render)" if (args.fused and eng.render_kernel != "pw_render_generic_kernel")
-                           else eng.render_kernel + (" (fused step + render)" if args.fused else "")),
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_measured_copy_6290": achieved / 6290.0,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo,
-                "avg_launch_ms": float(ms.mean()),
-                "min_launch_ms": float(ms.min()),
-                "rest_of_step_ms": 1000.0 * elapsed / K - float(ms.mean()),  # step kernel + launch gaps
-            }
-            out["config"]["algorithmic_bytes_per_env_step"] = eng.obs_bytes + state_bytes
+        out["config"]["algorithmic_bytes_per_env_step"] = eng.obs_bytes + state_bytes
+    else:
+        ms = np.array([a.elapsed_time(b) for a, b in step_events], dtype=np.float64)
+        algo = B * state_bytes
+        achieved = algo / (float(ms.mean()) * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "pw_step_group_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+            "algorithmic_bytes_per_launch": algo, "avg_launch_ms": float(ms.mean()),
+            "median_launch_ms": float(np.median(ms)), "min_launch_ms": float(ms.min()), "launches_timed": int(len(ms)),
+            "timer": "HIP events on the launch stream (torch current stream), rank 0",
+            "note": "state-only steps are latency / issue bound, far below the HBM roofline by construction",
+        }
+        out["config"]["algorithmic_bytes_per_env_step"] = state_bytes
+
+    if not args.no_extras:
         # extra (not the headline): the same loop with the observation buffer maintained incrementally
         # (pw_step_render_delta: same bytes in HBM after every step, only the changed pixel rows written)
         if obs_mode is not None:
             try:
                 def delta_step(t):
-                    eng.step_render_delta(vec.puzzle_id, actions[t], vec.pos, vec.steps, vec.reward, vec.dgoals,
+                    eng.step_render_delta(vec.puzzle_id, actions[t % n_act], vec.pos, vec.steps, vec.reward, vec.dgoals,
                                           vec.terminated, vec.truncated, vec._obs_storage, vec.flags)
                 for t in range(Wm):
                     delta_step(t)
@@ -285,7 +467,7 @@ def main():
                 dt = time.perf_counter() - t1
                 out["incremental_render"] = {
                     "env_steps_per_s": B * K / dt, "ms_per_step": 1000.0 * dt / K, "n_gpus": 1,
-                    "note": "pw_step_render_delta on this rank: observation buffer bit-identical to the full render "
+                    "note": "pw_step_render_delta on rank 0: observation buffer bit-identical to the full render "
                             "after every step (tests/test_gpu_incremental.py); not the headline value",
                 }
             except Exception as exc:  # noqa: BLE001
@@ -306,19 +488,18 @@ def main():
                                           "steps_per_launch": Tn, "envs": B, "n_gpus": 1}
         except Exception as exc:  # noqa: BLE001
             out["state_only_rollout"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline(paths, ids, args.max_steps, eng.obs_shape[0] // args.ppc,
-                                                   eng.obs_shape[1] // args.ppc, args.ppc, args.bw)
-                out["cpu_baseline"]["python_env"] = python_env_baseline(
-                    paths, ids, args.max_steps, eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc, args.ppc,
-                    args.bw)
-            except Exception as exc:  # noqa: BLE001
-                out["cpu_baseline"] = {"error": repr(exc)}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if not args.no_cpu_baseline:
+        # rank 0's host cores, also for N > 1 (the other ranks have finished; their processes are idle or gone)
+        fh, fw = eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl["texts"], wl["ids"], args.max_steps, obs_mode is not None, fh, fw,
+                                               args.ppc, args.bw, target_seconds=args.cpu_seconds)
+            out["cpu_baseline"]["python_env"] = python_env_baseline(
+                wl["texts"], wl["ids"], args.max_steps, obs_mode is not None, fh, fw, args.ppc, args.bw,
+                target_seconds=max(0.5, 0.3 * args.cpu_seconds))
+        except Exception as exc:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(exc)}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

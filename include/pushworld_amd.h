@@ -16,6 +16,9 @@
  *     `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
  *     are asynchronous on that stream; the engine never allocates per call (one exception:
  *     pw_step_render_delta allocates a 4 B / environment scratch on first use or batch growth).
+ *   - no entry point changes the calling thread's current HIP device: everything an engine /
+ *     set / search allocates or launches lands on the device of its puzzle set, and the
+ *     caller's device is restored on return.
  *   - calls on one engine must be externally serialised (like the reference
  *     objects, puzzle.py:310 / pushworld_puzzle.h:178-180, which are not
  *     re-entrant); different engines are independent.
@@ -38,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PW_ABI_VERSION 1
+#define PW_ABI_VERSION 2
 
 /* error codes */
 #define PW_OK 0
@@ -81,7 +84,8 @@ typedef struct PwPuzzleInfo {
 } PwPuzzleInfo;
 
 typedef struct PwEngineConfig {
-  int32_t max_steps;        /* <= 0: no truncation (gym_env.py:223)                       */
+  int32_t max_steps;        /* < 0: no truncation (max_steps=None, gym_env.py:223); >= 0:
+                               truncated = steps >= max_steps, so 0 truncates every step   */
   int32_t pixels_per_cell;  /* puzzle.py:26, >= 1 + 2 * border_width                      */
   int32_t border_width;     /* puzzle.py:22, >= 1                                         */
   int32_t obs_dtype;        /* PW_OBS_U8 | PW_OBS_F32                                     */
@@ -140,6 +144,37 @@ int64_t pw_engine_obs_bytes(const PwEngine* e);        /* h*w*c*sizeof(elem), un
 int pw_engine_render_kernel(const PwEngine* e, char* buf, int cap);
 int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride (16 B aligned) */
 
+/* Engine options: kernel selection for tests / A-B runs and profiling aids.  All 0 after
+ * pw_engine_create; none changes a result, only which kernel computes it. */
+#define PW_OPT_STEP_KERNEL 1       /* 0 lane group per env (default), 1 wavefront per env, 2 lane per env */
+#define PW_OPT_FUSED_STEP_RENDER 2 /* 1: pw_step_render is ONE launch (step inside the per-env render workgroups) */
+#define PW_OPT_RENDER_KERNEL 3     /* 0 automatic, 1 per-environment LDS kernel also where a page kernel applies */
+#define PW_OPT_PAGE_SLICE_ENVS 4   /* page kernels: environments per launch (0 = as many as 2^31 chunks allow) */
+#define PW_OPT_SEARCH_CHUNK 5      /* pw_search_create: parents per expansion pass (0 = 2^20) */
+#define PW_OPT_PROFILE_RENDER 6    /* n > 0: time the next n render launches with HIP events on their stream */
+#define PW_OPT_EXPERIMENT 7        /* bit field of A/B variants of the page-ordered render kernel (tools/experiments):
+                                      page order, store kind, occupancy limit, per-environment page records */
+int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
+int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
+/* Durations (milliseconds) of the render launches recorded since the last call, in launch order
+ * (PW_OPT_PROFILE_RENDER).  Waits for them to finish, writes at most `cap` values, returns how many
+ * were recorded and starts over. */
+int pw_engine_profile_read(PwEngine* e, float* ms, int32_t cap);
+
+/* Number of out-of-range actions (not in 0..3) the step kernels of this engine have seen since the
+ * last call; reads and clears the counter, synchronises `stream`.  An asynchronous caller that never
+ * looks at the 0xFF flags can poll this instead (an env flagged 0xFF is reset by the next
+ * PW_STEP_AUTORESET step, where the reference raises ValueError, gym_env.py:195-196). */
+int64_t pw_engine_bad_actions(PwEngine* e, void* stream);
+
+/* Debug check of the preconditions the kernels do not test (they index with these values):
+ * puzzle_id[i] inside the set; with `pos` != NULL also every movable inside its puzzle's grid
+ * (0 <= x <= W - w, 0 <= y <= H - h) and zero padding beyond the puzzle's movables.
+ * Synchronises `stream`.  Returns the number of offending environments (0 = fine; the lowest
+ * offending index goes to *first_bad when given) or a negative error. */
+int64_t pw_validate_state(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, int32_t batch,
+                          int32_t* first_bad, void* stream);
+
 /* gym_env.py:150-186 reset(): pos <- initial state of puzzle_id[e], steps <- 0,
  * terminated/truncated <- 0 (when given), for envs with mask[e] != 0 (mask NULL = all). */
 int pw_reset(PwEngine* e, const int32_t* puzzle_id, const uint8_t* mask, int8_t* pos,
@@ -171,9 +206,9 @@ int pw_resample(PwEngine* e, int32_t* puzzle_id, const uint8_t* terminated, cons
  *   terminated <- is_goal_state                        puzzle.py:409-411
  *   reward <- 10.0 | d(count_achieved_goals) - 0.01    gym_env.py:212-221 (float64)
  *   steps += 1; truncated <- steps >= max_steps        gym_env.py:201,223
- * reward / dgoals may be NULL.  Actions outside 0..3 leave the env untouched and set
- * terminated = truncated = 0xFF for that env (the wrappers validate on the host and raise
- * ValueError like gym_env.py:195-196). */
+ * reward / dgoals may be NULL.  Actions outside 0..3 leave the env untouched, set
+ * terminated = truncated = 0xFF for that env and bump the engine's sticky bad-action counter
+ * (pw_engine_bad_actions; the wrappers raise ValueError like gym_env.py:195-196). */
 int pw_step(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
             int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
             uint8_t* truncated, int32_t batch, uint32_t flags, void* stream);
@@ -194,7 +229,7 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
 int pw_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs,
               int64_t env_stride_bytes, int32_t batch, void* stream);
 
-/* pw_step followed by pw_render of the new state on the same stream (PUSHWORLD_AMD_FUSED=1 selects a
+/* pw_step followed by pw_render of the new state on the same stream (PW_OPT_FUSED_STEP_RENDER selects a
  * single launch that runs the step inside the per-environment render workgroups; slower, kept for tests). */
 int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
                    int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,

@@ -42,7 +42,7 @@ def lib():
         l.or_observation_f32.argtypes = [c_void_p, ip, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
         l.or_rollout.restype = c_uint64
         l.or_rollout.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_int, c_int, POINTER(c_uint8), c_int, c_int,
-                                 c_int, c_int, c_int, c_int, POINTER(c_int)]
+                                 c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]
         _lib = l
     return _lib
 
@@ -132,14 +132,15 @@ class COraclePuzzle:
         return out
 
 
-def rollout(puzzles, puzzle_ids, actions, max_steps, render, pad_h, pad_w, ppc, bw):
-    """Batched CPU baseline: ``actions`` uint8 [T][B].  Returns (checksum, threads used)."""
+def rollout(puzzles, puzzle_ids, actions, max_steps, render, pad_h, pad_w, ppc, bw, threads=0):
+    """Batched CPU baseline: ``actions`` uint8 [T][B]; ``threads`` <= 0 = all OpenMP threads.
+    Returns (checksum, threads used)."""
     handles = (c_void_p * len(puzzles))(*[p.handle for p in puzzles])
     pid = np.ascontiguousarray(np.asarray(puzzle_ids, dtype=np.int32))
     acts = np.ascontiguousarray(np.asarray(actions, dtype=np.uint8))
     T, B = acts.shape
     used = c_int(0)
     chk = lib().or_rollout(handles, pid.ctypes.data_as(POINTER(c_int32)), B, T,
-                           acts.ctypes.data_as(POINTER(c_uint8)), int(max_steps or 0), int(bool(render)),
-                           pad_h, pad_w, ppc, bw, ctypes.byref(used))
+                           acts.ctypes.data_as(POINTER(c_uint8)), int(-1 if max_steps is None else max_steps), int(bool(render)),
+                           pad_h, pad_w, ppc, bw, int(threads), ctypes.byref(used))
     return int(chk), used.value

@@ -340,14 +340,15 @@ void or_observation_f32(const OrPuzzle* p, const int* state, int pad_h, int pad_
  * `render` != 0 every step also renders the padded uint8 observation into a per-thread
  * buffer.  Returns a checksum so the work cannot be optimised away.  OpenMP over envs. */
 uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, const uint8_t* actions,
-                    int max_steps, int render, int pad_h, int pad_w, int ppc, int bw, int* threads_used) {
+                    int max_steps, int render, int pad_h, int pad_w, int ppc, int bw, int num_threads,
+                    int* threads_used) {
   uint64_t total = 0;
   int nthreads = 1;
 #ifdef _OPENMP
-  nthreads = omp_get_max_threads();
+  nthreads = num_threads > 0 ? num_threads : omp_get_max_threads(); /* num_threads <= 0: all */
 #endif
   if (threads_used) *threads_used = nthreads;
-#pragma omp parallel reduction(+ : total)
+#pragma omp parallel num_threads(nthreads) reduction(+ : total)
   {
     uint8_t* obs = NULL;
     uint8_t* scratch = NULL;
@@ -376,7 +377,7 @@ uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, 
         } else {
           const int term = or_env_step(p, state, actions[(size_t)t * B + b] & 3, &reward);
           steps++;
-          done = term || (max_steps > 0 && steps >= max_steps);
+          done = term || (max_steps >= 0 && steps >= max_steps);
         }
         if (render) {
           or_observation_u8(p, state, pad_h, pad_w, ppc, bw, obs, scratch);

@@ -119,7 +119,24 @@ SIGNATURES = {
          c_int64, c_int32, c_uint32, c_void_p],
     ),
     "pw_expand4": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "pw_engine_set_option": (c_int, [c_void_p, c_int32, c_int64]),
+    "pw_engine_get_option": (c_int64, [c_void_p, c_int32]),
+    "pw_engine_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_float), c_int32]),
+    "pw_engine_bad_actions": (c_int64, [c_void_p, c_void_p]),
+    "pw_validate_state": (c_int64, [c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
 }
+
+# pw_engine_set_option keys (include/pushworld_amd.h)
+OPTIONS = {
+    "step_kernel": 1,        # 0 / "group", 1 / "wave", 2 / "lane"
+    "fused_step_render": 2,
+    "render_kernel": 3,      # 0 / "auto", 1 / "lds"
+    "page_slice_envs": 4,
+    "search_chunk": 5,
+    "profile_render": 6,
+    "experiment": 7,
+}
+_OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1}
 
 
 def _load():
@@ -133,7 +150,7 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pw_abi_version() != 1:
+    if lib.pw_abi_version() != 2:
         raise ImportError("libpushworld_amd.so ABI version mismatch; rebuild it")
     return lib
 
@@ -300,9 +317,12 @@ class Engine:
     enqueue kernels on ``torch.cuda.current_stream()``."""
 
     def __init__(self, pset: PuzzleSet, max_steps=None, pixels_per_cell=20, border_width=2,
-                 obs_dtype=OBS_F32, pad_cell_height=0, pad_cell_width=0):
+                 obs_dtype=OBS_F32, pad_cell_height=0, pad_cell_width=0, options=None):
+        if max_steps is not None and int(max_steps) < 0:
+            raise ValueError("max_steps must be None or >= 0")
         cfg = PwEngineConfig(
-            int(max_steps) if max_steps is not None else 0,
+            # None = never truncate; 0 truncates on every step, like `steps >= max_steps` in gym_env.py:223
+            int(max_steps) if max_steps is not None else -1,
             int(pixels_per_cell), int(border_width), int(obs_dtype),
             int(pad_cell_height), int(pad_cell_width),
         )
@@ -318,9 +338,52 @@ class Engine:
         self.obs_bytes = lib.pw_engine_obs_bytes(h)
         self.obs_stride = lib.pw_engine_obs_stride(h)
         self.obs_dtype = torch.uint8 if obs_dtype == OBS_U8 else torch.float32
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
+
+    @property
+    def render_kernel(self) -> str:
+        """Name of the kernel ``pw_render`` launches for this engine (depends on the options)."""
         nb = ctypes.create_string_buffer(64)
-        check(lib.pw_engine_render_kernel(h, nb, 64))
-        self.render_kernel = nb.value.decode()
+        check(lib.pw_engine_render_kernel(self.handle, nb, 64))
+        return nb.value.decode()
+
+    def set_option(self, key, value) -> None:
+        """``pw_engine_set_option``: ``key`` is a name of ``OPTIONS`` (or its number), ``value`` an integer or
+        one of "group" / "wave" / "lane" (step_kernel), "auto" / "lds" (render_kernel)."""
+        k = OPTIONS[key] if isinstance(key, str) else int(key)
+        v = _OPTION_VALUES[value] if isinstance(value, str) else int(value)
+        check(lib.pw_engine_set_option(self.handle, k, v))
+
+    def get_option(self, key) -> int:
+        k = OPTIONS[key] if isinstance(key, str) else int(key)
+        return check(lib.pw_engine_get_option(self.handle, k))
+
+    def profile_render(self, launches: int) -> None:
+        """Time the next ``launches`` render launches with HIP events on their own stream."""
+        self.set_option("profile_render", launches)
+
+    def profile_read(self):
+        """Milliseconds of the render launches recorded since the last call (waits for them)."""
+        cap = self.get_option("profile_render")
+        buf = (ctypes.c_float * max(cap, 1))()
+        n = check(lib.pw_engine_profile_read(self.handle, buf, cap))
+        return [buf[i] for i in range(min(n, cap))]
+
+    def bad_actions(self) -> int:
+        """Out-of-range actions seen by this engine's step kernels since the last call (reads and clears the
+        sticky device counter; synchronises the stream)."""
+        return check(lib.pw_engine_bad_actions(self.handle, self._stream()))
+
+    def validate(self, puzzle_id, pos=None) -> None:
+        """``pw_validate_state``: raises ``ValueError`` when a puzzle id is outside the set or a movable outside
+        its puzzle's grid (the kernels index with both unchecked).  Synchronises the stream."""
+        first = c_int32(-1)
+        n = check(lib.pw_validate_state(self.handle, _ptr(puzzle_id), _ptr(pos), puzzle_id.shape[0], ctypes.byref(first),
+                                        self._stream()))
+        if n:
+            raise ValueError(f"{n} environment(s) with a puzzle id outside the set or a position outside the grid "
+                             f"(first: environment {first.value})")
 
     def _stream(self):
         return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

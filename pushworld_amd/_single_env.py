@@ -15,9 +15,26 @@ import torch
 
 from . import _capi
 from .config import PUZZLE_EXTENSION
-from .puzzle import NUM_ACTIONS, PushWorldPuzzle, default_device_index
+from .puzzle import PushWorldPuzzle, default_device_index
 from .utils.env_utils import get_max_puzzle_dimensions
 from .utils.filesystem import iter_files_with_extension
+
+
+def pool_frame(puzzles, standard_padding: bool):
+    """(height, width) in cells of the observation frame of a puzzle pool (gym_env.py:78-103): the pool maximum,
+    or the benchmark maximum with ``standard_padding`` (ValueError when the pool does not fit into it)."""
+    widths, heights = zip(*[p.dimensions for p in puzzles])
+    max_w, max_h = max(widths), max(heights)
+    if standard_padding:
+        std_h, std_w = get_max_puzzle_dimensions()
+        for what, std, own in (("height", std_h, max_h), ("width", std_w, max_w)):
+            if std < own:
+                raise ValueError(
+                    f"`standard_padding` is True, but the maximum puzzle {what} in BENCHMARK_PUZZLES_PATH is "
+                    f"less than the {what} of the puzzle(s) in the given `puzzle_path`."
+                )
+        max_h, max_w = std_h, std_w
+    return max_h, max_w
 
 
 class SingleEnvCore:
@@ -34,23 +51,7 @@ class SingleEnvCore:
         self._pixels_per_cell = pixels_per_cell
         self._border_width = border_width
 
-        widths, heights = zip(*[p.dimensions for p in self._puzzles])
-        self._max_cell_width = max(widths)
-        self._max_cell_height = max(heights)
-        if standard_padding:
-            std_h, std_w = get_max_puzzle_dimensions()
-            if std_h < self._max_cell_height:
-                raise ValueError(
-                    "`standard_padding` is True, but the maximum puzzle height in BENCHMARK_PUZZLES_PATH is "
-                    "less than the height of the puzzle(s) in the given `puzzle_path`."
-                )
-            self._max_cell_height = std_h
-            if std_w < self._max_cell_width:
-                raise ValueError(
-                    "`standard_padding` is True, but the maximum puzzle width in BENCHMARK_PUZZLES_PATH is "
-                    "less than the width of the puzzle(s) in the given `puzzle_path`."
-                )
-            self._max_cell_width = std_w
+        self._max_cell_height, self._max_cell_width = pool_frame(self._puzzles, standard_padding)
 
         # gym_env.py:107-109: fixed seed for reproducibility
         self._random_generator = random.Random(123)
@@ -131,6 +132,3 @@ class SingleEnvCore:
         return self._current_puzzle.render(self._current_state, border_width=self._border_width,
                                            pixels_per_cell=self._pixels_per_cell)
 
-
-def validate_num_actions():
-    return NUM_ACTIONS

@@ -19,6 +19,8 @@
 #include <map>
 #include <set>
 
+#include "pw_device_guard.h"
+
 static thread_local std::string g_last_error;
 
 void pw_set_error(const std::string& msg) { g_last_error = msg; }
@@ -294,7 +296,8 @@ int copy_cells(const std::vector<PwCell>& v, int32_t* xy, int cap) {
 static int upload_set(PwPuzzleSet* s) {
   if (s->device < 0) return PW_OK;
   const size_t n = static_cast<size_t>(s->count);
-  hipError_t err = hipSetDevice(s->device);
+  PwDeviceGuard guard(s->device);
+  hipError_t err = guard.status();
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&s->d_headers), n * sizeof(PwPuzzleHeader));
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&s->d_blob), s->blob.size());
   if (err == hipSuccess)
@@ -466,6 +469,55 @@ static uint64_t fnv1a64(const void* data, size_t n, uint64_t h) {
   return h;
 }
 
+// nullptr when the packed record is self-consistent, otherwise what is wrong with it
+static const char* pw_validate_packed_puzzle(const PwPuzzleHeader& h, const uint8_t* blob, uint64_t lim) {
+  if (h.W < 1 || h.W > PW_MAX_DIM || h.H < 1 || h.H > PW_MAX_DIM || h.N < 1 || h.N > PW_MAX_OBJECTS || h.G >= h.N)
+    return "puzzle dimensions out of range";
+  if (h.base > lim || (h.base & 7u)) return "table offsets out of range";
+  const uint64_t room = lim - h.base;
+  auto inside = [&](uint64_t off, uint64_t bytes, uint64_t align) {
+    return off <= room && bytes <= room - off && (off % align) == 0;
+  };
+  uint32_t shape_rows = 0;
+  for (int j = 0; j < h.N; j++) {
+    const PwObjEntry& o = h.objtab[j];
+    if (o.w < 1 || o.h < 1 || o.w > h.W || o.h > h.H) return "object bounding box out of range";
+    shape_rows = std::max<uint32_t>(shape_rows, static_cast<uint32_t>(o.row_off) + o.h);
+    const int x = h.init[j][0], y = h.init[j][1];
+    if (x < 0 || y < 0 || x + o.w > h.W || y + o.h > h.H) return "initial position outside the grid";
+  }
+  for (int g = 0; g < h.G; g++) {
+    const int x = h.goal[g][0], y = h.goal[g][1];
+    if (x < 0 || y < 0 || x >= h.W || y >= h.H) return "goal position outside the grid";
+  }
+  if (!inside(h.off_wall, 8ull * h.H, 8) || !inside(h.off_awall, 8ull * h.H, 8) ||
+      !inside(h.off_shapes, 8ull * shape_rows, 8) || !inside(h.off_static, 4ull * h.W * h.H, 4) ||
+      !inside(h.off_mcells, 4ull * std::max<uint32_t>(h.n_mcells, 1u), 4) || h.n_mcells > 64u * 64u)
+    return "table offsets out of range";
+  const uint64_t width_mask = h.W >= 64 ? ~0ull : ((1ull << h.W) - 1ull);
+  const uint64_t* wall = reinterpret_cast<const uint64_t*>(blob + h.base + h.off_wall);
+  const uint64_t* awall = reinterpret_cast<const uint64_t*>(blob + h.base + h.off_awall);
+  for (int y = 0; y < h.H; y++)
+    if ((wall[y] & ~width_mask) || (awall[y] & ~width_mask)) return "wall rows reach outside the grid";
+  const uint64_t* shapes = reinterpret_cast<const uint64_t*>(blob + h.base + h.off_shapes);
+  for (int j = 0; j < h.N; j++) {
+    const PwObjEntry& o = h.objtab[j];
+    const uint64_t m = o.w >= 64 ? ~0ull : ((1ull << o.w) - 1ull);
+    for (int r = 0; r < o.h; r++)
+      if (shapes[o.row_off + r] & ~m) return "shape rows reach outside the bounding box";
+  }
+  const uint32_t* mcells = reinterpret_cast<const uint32_t*>(blob + h.base + h.off_mcells);
+  for (uint32_t i = 0; i < h.n_mcells; i++) {
+    const uint32_t c = mcells[i];
+    const uint32_t obj = c >> 24, cx = c & 0xffu, cy = (c >> 8) & 0xffu;
+    if (obj >= h.N || cx >= h.objtab[obj].w || cy >= h.objtab[obj].h) return "movable cell list out of range";
+  }
+  const uint32_t* codes = reinterpret_cast<const uint32_t*>(blob + h.base + h.off_static);
+  for (int i = 0; i < h.W * h.H; i++)
+    if (((codes[i] >> PW_CODE_KIND_SHIFT) & 0xfu) > 2u || ((codes[i] >> 12) & 0xfffu)) return "static cell codes out of range";
+  return nullptr;
+}
+
 extern "C" {
 
 int pw_puzzleset_save(const PwPuzzleSet* s, const char* path) {
@@ -525,14 +577,12 @@ int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) {
     return bad(ok ? "checksum mismatch" : "truncated file");
   }
   std::fclose(f);
-  // every table offset must lie inside the blob: the kernels index with them unchecked
+  // The kernels index with every field below unchecked (LDS writes included), and FNV-1a is no protection
+  // against a crafted file: validate the full extent of every section and every index stored in them.
   for (const PwPuzzleHeader& h : s->headers) {
-    const uint64_t lim = s->blob.size();
-    if (h.W < 1 || h.W > PW_MAX_DIM || h.H < 1 || h.H > PW_MAX_DIM || h.N < 1 || h.N > PW_MAX_OBJECTS || h.G >= h.N ||
-        h.base > lim || h.base + h.off_wall > lim || h.base + h.off_awall > lim || h.base + h.off_shapes > lim ||
-        h.base + h.off_static > lim || h.base + h.off_mcells + 4ull * h.n_mcells > lim) {
+    if (const char* why = pw_validate_packed_puzzle(h, s->blob.data(), s->blob.size())) {
       delete s;
-      return pw_fail(PW_EPARSE, std::string(path) + ": table offsets out of range");
+      return pw_fail(PW_EPARSE, std::string(path) + ": " + why);
     }
   }
   if (int rc = upload_set(s)) return rc;

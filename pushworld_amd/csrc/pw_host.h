@@ -39,4 +39,10 @@ struct PwPuzzleSet {
 void pw_set_error(const std::string& msg);
 int pw_fail(int code, const std::string& msg);
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the guard and restores the caller's
+// device afterwards: no entry point of the C ABI changes the caller's current device (and therefore
+// torch.cuda.current_device()), and everything an entry point allocates or launches lands on the device of the
+// puzzle set it works on.  pw_host.cpp / pw_kernels.hip define it after including the HIP runtime.
+struct PwDeviceGuard;
+
 #endif  // PW_HOST_H_

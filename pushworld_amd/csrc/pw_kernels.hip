@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "pw_host.h"
+#include "pw_device_guard.h"
 #include "pw_zone.h"
 
 #define PW_WAVE 64
@@ -47,8 +48,19 @@ struct PwEngine {
                            // frame-layout zone table (the generic LDS kernel keeps its own layout)
   uint16_t* d_estat_page;
   uint32_t* d_estat_page_off;
-  int step_kernel;         // 0 group (default), 1 wavefront per env, 2 lane per env (PUSHWORLD_AMD_STEP)
-  bool force_fused;        // PUSHWORLD_AMD_FUSED=1: pw_step_render always uses the single fused launch
+  // test / profiling knobs, pw_engine_set_option (all 0 by default)
+  int step_kernel;         // PW_OPT_STEP_KERNEL: 0 lane group (default), 1 wavefront per env, 2 lane per env
+  bool force_fused;        // PW_OPT_FUSED_STEP_RENDER: pw_step_render always uses the single fused launch
+  bool force_lds_render;   // PW_OPT_RENDER_KERNEL = 1: per-environment LDS kernel even where the page kernel applies
+  int64_t page_slice_envs; // PW_OPT_PAGE_SLICE_ENVS: environments per page-kernel launch (0 = what 2^31 chunks allow)
+  int64_t search_chunk;    // PW_OPT_SEARCH_CHUNK: parents per pw_search_expand pass (0 = 2^20)
+  int64_t experiment;      // PW_OPT_EXPERIMENT: A/B variants of the page kernel (CopyArgs::xp), never a different result
+  void* d_rec;             // page records (PageRec [rec_cap]), grown on demand
+  int64_t rec_cap;
+  // PW_OPT_PROFILE_RENDER: HIP event pairs around the dominant (render) launch, on the launch stream
+  std::vector<hipEvent_t> prof_events;  // 2 per slot
+  int prof_used;
+  uint32_t* d_scratch;     // 64 bytes of device scratch (pw_validate_state counters)
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)

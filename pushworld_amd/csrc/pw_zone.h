@@ -11,7 +11,7 @@
 
 #include "pw_format.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PW_HD __host__ __device__ __forceinline__
 #else
 #define PW_HD inline

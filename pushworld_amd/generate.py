@@ -100,22 +100,21 @@ def solve(puzzle_text: str, max_states: int = 2_000_000, time_limit: Optional[fl
     for width in (2, 0):
         bfs = BreadthFirstSearch(puzzle, max_states=max_states, novelty_width=width)
         bfs.begin()
+        full = False
         try:
             while bfs.goal_index < 0 and not bfs.exhausted:
                 if time_limit is not None and time.perf_counter() - t0 > time_limit:
                     return None, "unknown"
                 bfs.expand()
-        except ValueError:  # store full
-            if width == 0:
-                return None, "unknown"
-            continue
+        except ValueError:  # store full: the last layer is incomplete, but a goal found in it is still a goal
+            full = True
         finally:
             plan = bfs.plan(bfs.goal_index) if bfs.goal_index >= 0 else None
             bfs.close()
         if plan is not None:
             return plan, "solved"
         if width == 0:
-            return None, "unsolvable"
+            return None, ("unknown" if full else "unsolvable")
     return None, "unknown"
 
 

@@ -35,12 +35,14 @@ class BreadthFirstSearch:
     Args:
         puzzle: a ``PushWorldPuzzle`` (object order as parsed: Python order by default).
         max_states: capacity of the state store (device memory ~ ``max_states * (2 N + 21)`` bytes).
+        chunk: parents per expansion pass (default 2^20; tests use small values to force many passes per layer).
         novelty_width: 0 = breadth-first search; 1 or 2 = width-limited search IW(k): new states whose
             novelty (reference ``NoveltyHeuristic``, novelty.cc:30-77) exceeds the width are closed but
             never expanded.  Incomplete but usually far smaller; plans are no longer guaranteed shortest.
     """
 
-    def __init__(self, puzzle: PushWorldPuzzle, max_states: int = 1 << 22, novelty_width: int = 0):
+    def __init__(self, puzzle: PushWorldPuzzle, max_states: int = 1 << 22, novelty_width: int = 0,
+                 chunk: Optional[int] = None):
         self.puzzle = puzzle
         self._engine = puzzle._engine()
         self.device = self._engine.device
@@ -48,8 +50,12 @@ class BreadthFirstSearch:
         self.max_states = int(max_states)
         h = ctypes.c_void_p()
         self.novelty_width = int(novelty_width)
-        _capi.check(_capi.lib.pw_search_create(self._engine.handle, 0, self.max_states, self.novelty_width,
-                                               ctypes.byref(h)))
+        self._engine.set_option("search_chunk", 0 if chunk is None else int(chunk))
+        try:
+            _capi.check(_capi.lib.pw_search_create(self._engine.handle, 0, self.max_states, self.novelty_width,
+                                                   ctypes.byref(h)))
+        finally:
+            self._engine.set_option("search_chunk", 0)
         self.handle = h
         self.total_states = 0
         self.layers: List[Tuple[int, int]] = []  # (first index, count) per depth

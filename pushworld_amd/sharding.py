@@ -28,6 +28,49 @@ def shard_puzzle_ids(puzzle_ids, rank: int, world: int):
     return puzzle_ids[lo:hi]
 
 
+def c4_global_puzzle_ids(total_envs: int, n_level0: int, n_higher: int, seed: int = 100):
+    """Puzzle of every environment of config C4 over the WHOLE job, independent of the number of
+    ranks: even environments draw uniformly from the ``n_level0`` Level-0 train puzzles (pool indices
+    0 .. n_level0 - 1), odd ones from the ``n_higher`` Level-1..4 puzzles (indices n_level0 ..) -- a 50 / 50 mix.
+    Every rank computes the same array and keeps its ``shard_puzzle_ids`` slice (sorted inside the shard so that
+    environments of one puzzle sit together)."""
+    import numpy as np
+
+    if total_envs < 0 or n_level0 < 1 or n_higher < 1:
+        raise ValueError("c4_global_puzzle_ids: empty puzzle pool")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lo = rng.integers(0, n_level0, size=total_envs, dtype=np.int64)
+    hi = rng.integers(0, n_higher, size=total_envs, dtype=np.int64) + n_level0
+    return np.where(np.arange(total_envs) % 2 == 0, lo, hi)
+
+
+def _group():
+    import torch.distributed as dist
+
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def reduce_max(values, device=None):
+    """Element-wise MAX over all ranks of a list of floats (identity without a process group)."""
+    dist = _group()
+    if dist is None:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+def gather_floats(value: float, device=None):
+    """One float of every rank, in rank order (``[value]`` without a process group)."""
+    dist = _group()
+    if dist is None:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def reduce_counters(counters: Dict[str, int], elapsed_s: float, device=None) -> Tuple[Dict[str, int], float]:
     """SUM of integer counters and MAX of the elapsed time over all ranks (identity when
     torch.distributed is not initialised)."""

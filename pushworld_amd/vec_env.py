@@ -46,6 +46,8 @@ class VecPushWorld:
             Draws happen in ``reset`` (all / masked environments) and, with ``autoreset``, at the
             start of the ``step`` that resets a finished environment.
         seed: seed of the counter-based draw: puzzle = f(seed, environment index, episode number).
+        engine_options: ``pw_engine_set_option`` settings (``_capi.OPTIONS``), e.g. ``{"step_kernel": "lane"}`` --
+            kernel selection for tests and A/B runs; results never depend on them.
     """
 
     def __init__(self, puzzles: Sequence[Union[str, PushWorldPuzzle]], num_envs: int,
@@ -53,7 +55,7 @@ class VecPushWorld:
                  border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
                  autoreset: bool = False, fused: bool = False, resample=False, seed: int = 0,
-                 incremental: bool = False):
+                 incremental: bool = False, engine_options: Optional[dict] = None):
         if observation not in ("uint8", "float32", None):
             raise ValueError("observation must be 'uint8', 'float32' or None")
         dev = default_device_index() if device is None else int(device)
@@ -70,7 +72,8 @@ class VecPushWorld:
         self.num_puzzles = len(self.pset)
         ph, pw = pad_cells if pad_cells is not None else (0, 0)
         dtype = _capi.OBS_F32 if observation == "float32" else _capi.OBS_U8
-        self.engine = _capi.Engine(self.pset, max_steps, pixels_per_cell, border_width, dtype, ph, pw)
+        self.engine = _capi.Engine(self.pset, max_steps, pixels_per_cell, border_width, dtype, ph, pw,
+                                   options=engine_options)
         self.device = self.engine.device
         self.num_envs = int(num_envs)
         self.observation = observation

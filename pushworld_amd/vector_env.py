@@ -19,7 +19,7 @@ import torch
 from . import _compat
 from .config import PUZZLE_EXTENSION
 from .puzzle import DEFAULT_BORDER_WIDTH, DEFAULT_PIXELS_PER_CELL, NUM_ACTIONS, PushWorldPuzzle
-from .utils.env_utils import get_max_puzzle_dimensions
+from ._single_env import pool_frame
 from .utils.filesystem import iter_files_with_extension
 from .vec_env import VecPushWorld
 
@@ -60,22 +60,7 @@ def _load_pool(puzzle_path, standard_padding: bool):
         puzzles = [PushWorldPuzzle(p) for p in iter_files_with_extension(puzzle_path, PUZZLE_EXTENSION)]
     if len(puzzles) == 0:
         raise ValueError(f"No PushWorld puzzles found in: {puzzle_path}")
-    widths, heights = zip(*[p.dimensions for p in puzzles])
-    max_w, max_h = max(widths), max(heights)
-    if standard_padding:
-        std_h, std_w = get_max_puzzle_dimensions()
-        if std_h < max_h:
-            raise ValueError(
-                "`standard_padding` is True, but the maximum puzzle height in BENCHMARK_PUZZLES_PATH is "
-                "less than the height of the puzzle(s) in the given `puzzle_path`."
-            )
-        if std_w < max_w:
-            raise ValueError(
-                "`standard_padding` is True, but the maximum puzzle width in BENCHMARK_PUZZLES_PATH is "
-                "less than the width of the puzzle(s) in the given `puzzle_path`."
-            )
-        max_h, max_w = std_h, std_w
-    return puzzles, (max_h, max_w)
+    return puzzles, pool_frame(puzzles, standard_padding)
 
 
 class _VectorCore:
@@ -115,7 +100,10 @@ class _VectorCore:
             if a.shape != (self.num_envs,) or a.dtype in (torch.bool, torch.float16, torch.float32, torch.float64, torch.bfloat16):
                 raise ValueError("The provided action is not in the action space.")
             if a.device != self.vec.device or a.dtype != torch.uint8:
-                if a.device.type == "cpu" and ((a < 0) | (a >= NUM_ACTIONS)).any():
+                # Wider integer types are range-checked BEFORE the cast (256 would become LEFT, -1 would become
+                # 255): one fused reduction where the tensor lives; on the device this synchronises, which the
+                # conversion path can afford -- pass uint8 device tensors to stay asynchronous.
+                if bool(((a < 0) | (a >= NUM_ACTIONS)).any()):
                     raise ValueError("The provided action is not in the action space.")
                 a = a.to(device=self.vec.device, dtype=torch.uint8)
             return a
@@ -141,8 +129,18 @@ class _VectorCore:
         if self.to_numpy:  # the .cpu() copies synchronise; device tensors stay stream-ordered
             bad = v.terminated.cpu().numpy() == 0xFF
             if bad.any():  # device-side action check of pw_step (action outside 0..3)
+                v.engine.bad_actions()  # reported here: clear the sticky counter
                 raise ValueError("The provided action is not in the action space.")
         return v.obs, v.reward, v.terminated, v.truncated
+
+    def check_actions(self) -> None:
+        """Device-tensor mode (``to_numpy=False``) never synchronises, so a uint8 action outside 0..3 cannot raise
+        inside ``step``: the kernel leaves that environment untouched, flags it 0xFF (the next step then resets
+        it) and counts it in the engine's sticky counter.  This reads and clears the counter (one stream
+        synchronisation) and raises the reference's ``ValueError`` (gym_env.py:195-196) if any was seen."""
+        n = self.vec.engine.bad_actions()
+        if n:
+            raise ValueError(f"The provided action is not in the action space. ({n} since the last check)")
 
     def close(self) -> None:
         self._closed = True

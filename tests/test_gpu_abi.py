@@ -1,0 +1,219 @@
+"""-m gpu: the parts of the C ABI that are not dynamics -- engine options (former environment variables),
+pw_validate_state, the sticky bad-action counter, max_steps = 0, the render profiler and the rule that no entry
+point changes the caller's current HIP device."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def _level1_vec(B=512, **kw):
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    args = dict(puzzle_ids=ids, max_steps=50, pixels_per_cell=3, border_width=1, observation="uint8", device=0,
+                autoreset=True)
+    args.update(kw)
+    return VecPushWorld([PushWorldPuzzle(p) for p in paths], B, **args)
+
+
+def test_engine_options_round_trip_and_select_kernels(torch_mod):
+    from pushworld_amd import _capi
+
+    vec = _level1_vec()
+    eng = vec.engine
+    for name in _capi.OPTIONS:
+        assert eng.get_option(name) == 0
+    assert eng.render_kernel == "pw_render_page_kernel"
+    eng.set_option("render_kernel", "lds")
+    assert eng.get_option("render_kernel") == 1 and eng.render_kernel == "pw_render_u8_ppc3_kernel"
+    eng.set_option("render_kernel", "auto")
+    eng.set_option("step_kernel", "lane")
+    assert eng.get_option("step_kernel") == 2
+    eng.set_option("page_slice_envs", 100)
+    assert eng.get_option("page_slice_envs") == 100
+    for bad in (("step_kernel", 3), ("render_kernel", 2), ("page_slice_envs", -1), (99, 0)):
+        with pytest.raises(ValueError):
+            eng.set_option(*bad)
+    # options never change results: same walk with every combination
+    torch = torch_mod
+    ref = _level1_vec()
+    alt = _level1_vec(engine_options={"step_kernel": "wave", "render_kernel": "lds"})
+    o0, o1 = ref.reset(), alt.reset()
+    assert torch.equal(o0, o1)
+    g = torch.Generator(device=ref.device).manual_seed(3)
+    for t in range(12):
+        a = torch.randint(0, 4, (ref.num_envs,), generator=g, device=ref.device, dtype=torch.uint8)
+        r0, r1 = ref.step(a), alt.step(a)
+        for x, y in zip(r0, r1):
+            assert torch.equal(x, y), t
+        assert torch.equal(ref.pos, alt.pos)
+
+
+def test_render_profiler_times_every_launch(torch_mod):
+    torch = torch_mod
+    vec = _level1_vec(B=2048)
+    vec.reset()
+    eng = vec.engine
+    assert eng.profile_read() == []
+    eng.profile_render(5)
+    a = torch.zeros((vec.num_envs,), dtype=torch.uint8, device=vec.device)
+    for _ in range(7):  # two launches more than slots: they are simply not timed
+        vec.step(a)
+    ms = eng.profile_read()
+    assert len(ms) == 5 and all(0.0 < m < 50.0 for m in ms)
+    assert eng.profile_read() == []          # reading starts over
+    vec.step(a)
+    assert len(eng.profile_read()) == 1
+    eng.profile_render(0)
+    vec.step(a)
+    assert eng.profile_read() == []
+
+
+def test_validate_state_catches_what_the_kernels_do_not_check(torch_mod):
+    torch = torch_mod
+    vec = _level1_vec(B=300)
+    vec.reset()
+    eng = vec.engine
+    eng.validate(vec.puzzle_id, vec.pos)      # a reset batch is fine
+    eng.validate(vec.puzzle_id)               # ids only
+    ids = vec.puzzle_id.clone()
+    ids[17] = vec.num_puzzles                 # one past the set
+    ids[200] = -1
+    with pytest.raises(ValueError, match=r"2 environment\(s\).*environment 17"):
+        eng.validate(ids, vec.pos)
+    pos = vec.pos.clone()
+    pos[5, 0, 0] = 63                          # agent's right edge beyond the grid
+    pos[9, 15, 1] = 1                          # non-zero padding slot (no Level-1 puzzle has 16 movables)
+    with pytest.raises(ValueError, match=r"2 environment\(s\).*environment 5"):
+        eng.validate(vec.puzzle_id, pos)
+    pos[:] = vec.pos
+    pos[0, 0, 1] = -1
+    with pytest.raises(ValueError, match="environment 0"):
+        eng.validate(vec.puzzle_id, pos)
+    # every state of a random walk stays valid (legal play keeps objects inside the border walls)
+    g = torch.Generator(device=vec.device).manual_seed(0)
+    for _ in range(30):
+        vec.step(torch.randint(0, 4, (vec.num_envs,), generator=g, device=vec.device, dtype=torch.uint8))
+    eng.validate(vec.puzzle_id, vec.pos)
+
+
+@pytest.mark.parametrize("kernel", ["group", "wave", "lane"])
+def test_bad_actions_are_flagged_and_counted(torch_mod, kernel):
+    torch = torch_mod
+    vec = _level1_vec(B=256, observation=None, autoreset=False, engine_options={"step_kernel": kernel})
+    vec.reset()
+    before = vec.pos.clone()
+    a = torch.zeros((256,), dtype=torch.uint8, device=vec.device)
+    a[3], a[100], a[255] = 4, 255, 9
+    vec.step(a)
+    term, trunc = vec.terminated.cpu().numpy(), vec.truncated.cpu().numpy()
+    bad = np.zeros(256, bool)
+    bad[[3, 100, 255]] = True
+    assert (term[bad] == 0xFF).all() and (trunc[bad] == 0xFF).all() and (term[~bad] != 0xFF).all()
+    assert torch.equal(vec.pos[bad], before[bad])           # untouched
+    assert vec.engine.bad_actions() == 3
+    assert vec.engine.bad_actions() == 0                    # read-and-clear
+    vec.step(torch.ones((256,), dtype=torch.uint8, device=vec.device))
+    assert vec.engine.bad_actions() == 0
+
+
+def test_vector_env_rejects_out_of_range_device_actions(torch_mod):
+    """a device int64 action tensor was cast to uint8 unchecked (256 -> LEFT, -1 -> 255) and, with
+    to_numpy=False, the 0xFF flags were never looked at."""
+    torch = torch_mod
+    import bench
+    from pushworld_amd.vector_env import PushWorldVectorEnv
+
+    env = PushWorldVectorEnv(bench.level1_paths()[:5], 16, max_steps=20, border_width=1, pixels_per_cell=3,
+                             observation="uint8", to_numpy=False)
+    env.reset(seed=1)
+    dev = env.vec.device
+    for bad in (256, -1, 4):
+        a = torch.zeros((16,), dtype=torch.int64, device=dev)
+        a[7] = bad
+        with pytest.raises(ValueError, match="not in the action space"):
+            env.step(a)
+    env.step(torch.full((16,), 3, dtype=torch.int64, device=dev))   # in range: accepted and cast
+    env.check_actions()
+    a8 = torch.zeros((16,), dtype=torch.uint8, device=dev)
+    a8[2] = 200                                                      # uint8 fast path: no synchronisation in step
+    env.step(a8)
+    with pytest.raises(ValueError, match=r"\(1 since the last check\)"):
+        env.check_actions()
+    env.check_actions()                                              # cleared
+
+
+def test_max_steps_zero_truncates_every_step(torch_mod, golden):
+    """gym_env.py:223 ``truncated = steps >= max_steps``: 0 truncates at once, only None never does (ADVICE r1:
+    0 used to be encoded as "no limit")."""
+    torch = torch_mod
+    from oracle import pw_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    key = "bench:level1/2 Obstacle.pwp"
+    oz = pw_oracle.OraclePuzzle(golden.text(key))
+    for max_steps in (0, 1, None):
+        vec = VecPushWorld([PushWorldPuzzle(text=golden.text(key))], 4, max_steps=max_steps, observation=None, device=0)
+        vec.reset()
+        oenv = pw_oracle.OracleEnv(oz, max_steps)
+        oenv.reset()
+        for a in (0, 2, 1, 3, 3):
+            _, r, te, tr = vec.step(torch.full((4,), a, dtype=torch.uint8, device=vec.device))
+            _, orew, oterm, otrunc = oenv.step(a)
+            assert (tr.cpu().numpy() == int(otrunc)).all() and (te.cpu().numpy() == int(oterm)).all(), (max_steps, a)
+            assert (r.cpu().numpy() == orew).all()
+    with pytest.raises(ValueError):
+        VecPushWorld([PushWorldPuzzle(text=golden.text(key))], 4, max_steps=-2, observation=None, device=0)
+
+
+def test_entry_points_leave_the_current_device_alone(torch_mod, golden):
+    """pw_engine_create / pw_search_create / novelty / upload called hipSetDevice and never
+    restored it, and pw_step_render_delta allocated its scratch on whatever device was current.  With two
+    devices: everything of an engine on device 1 works while the caller's current device stays 0."""
+    torch = torch_mod
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.search import BreadthFirstSearch, NoveltyTables
+    from pushworld_amd.vec_env import VecPushWorld
+
+    n = torch.cuda.device_count()
+    target = 1 if n >= 2 else 0
+    torch.cuda.set_device(0)
+    key = "bench:level1/2 Obstacle.pwp"
+    pz = PushWorldPuzzle(text=golden.text(key))
+    vec = VecPushWorld([pz], 64, max_steps=9, pixels_per_cell=3, border_width=1, observation="uint8", device=target,
+                       autoreset=True, incremental=True)
+    assert torch.cuda.current_device() == 0
+    ref = VecPushWorld([pz], 64, max_steps=9, pixels_per_cell=3, border_width=1, observation="uint8", device=target,
+                       autoreset=True)
+    o0, o1 = vec.reset().clone(), ref.reset().clone()
+    assert torch.equal(o0, o1) and torch.cuda.current_device() == 0
+    g = torch.Generator(device=vec.device).manual_seed(5)
+    for t in range(25):
+        a = torch.randint(0, 4, (64,), generator=g, device=vec.device, dtype=torch.uint8)
+        oa, ob = vec.step(a)[0], ref.step(a)[0]       # incremental path allocates its dirty-row scratch lazily
+        assert torch.equal(oa, ob), t
+        assert torch.cuda.current_device() == 0
+    vec.engine.validate(vec.puzzle_id, vec.pos)
+    assert vec.engine.bad_actions() == 0 and torch.cuda.current_device() == 0
+    nt = NoveltyTables(3, 8, 8, device=target)
+    nt.reset()
+    assert torch.cuda.current_device() == 0
+    if target == 0:
+        bfs = BreadthFirstSearch(pz, max_states=4096, novelty_width=1)
+        bfs.begin()
+        bfs.expand()
+        assert bfs.total_states > 1 and torch.cuda.current_device() == 0
+        bfs.close()

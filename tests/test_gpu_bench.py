@@ -1,0 +1,83 @@
+"""-m gpu: bench.py as the driver runs it -- the self-spawned multi-rank path, the refusal to
+measure fewer ranks than asked, the C4 shard and the shape of the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-extras"]
+
+
+def run_bench(*argv, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    return proc, [json.loads(l) for l in lines]
+
+
+def test_self_spawned_two_ranks_sum_their_counters():
+    """``python bench.py --gpus 2`` (no torchrun) starts two ranks itself.  With one device on the box both ranks
+    share it and the counters go over gloo (RCCL refuses two ranks on one GPU); with two or more it is the real
+    one-rank-per-GPU RCCL path.  ONE JSON line, n_gpus == 2, counters summed, cpu_baseline kept for N > 1."""
+    import torch
+
+    shared = [] if torch.cuda.device_count() >= 2 else ["--shared-device"]
+    proc, lines = run_bench("--gpus", "2", *shared, *SMALL, "--cpu-seconds", "1")
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["global_batch"] == 2 * 2048 and d["config"]["envs_per_gpu"] == 2048
+    # value = (sum over ranks of envs x steps) / median window: both ranks' steps are in it
+    assert abs(d["value"] - 2 * 2048 * 3 / (d["ms_per_step"] * 3 / 1000.0)) < 1e-6 * d["value"]
+    assert len(d["timing"]["per_rank_median_ms_per_step"]) == 2 and len(d["timing"]["window_ms_per_step"]) == 2
+    assert d["timing"]["min_ms_per_step"] <= d["ms_per_step"] <= d["timing"]["max_ms_per_step"]
+    assert ("gloo" if shared else "nccl") in d["config"]["parallelism"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["launches_timed"] == 6 and r["traffic"] is None
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["one_thread"]["cores"] == 1 and cb["cpu_model"]
+    assert cb["python_env"]["value"] > 0 and cb["python_env"]["processes"]["cores"] >= 1
+
+
+def test_more_ranks_than_devices_is_refused():
+    """--gpus N with fewer than N devices must fail, not report n_gpus 1 (missing #1)."""
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    proc, lines = run_bench("--gpus", str(n), *SMALL, "--no-cpu-baseline", timeout=120)
+    assert proc.returncode != 0 and not lines
+    assert "device" in proc.stderr
+
+
+def test_single_rank_line_has_the_contract_fields():
+    proc, lines = run_bench(*SMALL, "--no-cpu-baseline")
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "timing"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "u8" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("C3") and d["roofline"]["kernel"].startswith("pw_render")
+
+
+@pytest.mark.parametrize("obs", ["none", "uint8"])
+def test_c4_shard_runs(obs):
+    """--config c4: the rank's shard of the full mix (all 14 000 Level-0 train puzzles + Levels 1-4, N_pad 32,
+    frame 54 x 47), state only and with the uint8 ppc-3 render."""
+    proc, lines = run_bench("--config", "c4", "--obs", obs, *SMALL, "--no-cpu-baseline")
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    d = lines[0]
+    assert d["config"]["config"] == "c4" and d["config"]["puzzles"] == 14223 and d["config"]["n_pad"] == 32
+    assert d["config"]["frame_cells"] == [54, 47]
+    assert d["roofline"]["kernel"] == ("pw_step_group_kernel" if obs == "none" else d["roofline"]["kernel"])
+    assert d["value"] > 0

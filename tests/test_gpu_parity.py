@@ -48,7 +48,6 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
     pw_step has three kernels (16/32 lanes per env = default, one lane per env, one wavefront per
     env); all are checked."""
     torch = torch_mod
-    monkeypatch.setenv("PUSHWORLD_AMD_STEP", kernel)
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = _groups(golden)[group]
@@ -60,7 +59,8 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
     B = len(envs)
     T = max(len(e[2][1]) for e in envs)
     max_steps = 50
-    vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=max_steps, observation=None, device=0)
+    vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=max_steps, observation=None, device=0,
+                       engine_options={"step_kernel": kernel})
     vec.reset()
     NP = vec.num_objects_padded
     # start states
@@ -104,7 +104,6 @@ def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypat
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
     torch = torch_mod
-    monkeypatch.setenv("PUSHWORLD_AMD_STEP", kernel)
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = [k for k in golden.keys if f"{k}|in" in golden.states]
@@ -116,7 +115,7 @@ def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypat
             ids.append(pi)
             rows.append((k, s))
     B = len(ids)
-    vec = VecPushWorld(pool, B, puzzle_ids=ids, observation=None, device=0)
+    vec = VecPushWorld(pool, B, puzzle_ids=ids, observation=None, device=0, engine_options={"step_kernel": kernel})
     vec.reset()
     NP = vec.num_objects_padded
     base = np.zeros((B, NP, 2), np.int8)
@@ -197,7 +196,7 @@ def test_full_small_images(golden, puzzles, torch_mod):
 @pytest.mark.parametrize("path", ["page"])
 def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monkeypatch):
     """The page-ordered render kernel (default for uint8 / ppc 3: static-image copy + LDS entry window)
-    and the per-environment LDS kernel (PUSHWORLD_AMD_RENDER=lds) produce byte-identical observations
+    and the per-environment LDS kernel (engine option render_kernel = "lds") produce byte-identical observations
     on a mixed Level-1 batch along random walks and on overlapping (illegal) states."""
     torch = torch_mod
     import bench
@@ -208,14 +207,13 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     B, T = 2048, 25
     ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
 
-    def make():
+    def make(kernel):
         return VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, pixels_per_cell=3,
-                            border_width=1, observation=obs_kind, device=0, autoreset=True)
+                            border_width=1, observation=obs_kind, device=0, autoreset=True,
+                            engine_options={"render_kernel": kernel})
 
-    monkeypatch.setenv("PUSHWORLD_AMD_RENDER", "lds")
-    ref = make()
-    monkeypatch.setenv("PUSHWORLD_AMD_RENDER", path)
-    alt = make()
+    ref = make("lds")
+    alt = make(path)
     assert ref.engine.render_kernel != "pw_render_page_kernel" and alt.engine.render_kernel == "pw_render_page_kernel"
     o_ref, o_alt = ref.reset(), alt.reset()
     assert torch.equal(o_ref, o_alt)
@@ -248,8 +246,7 @@ def test_page_render_in_slices(golden, torch_mod, monkeypatch):
     ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
     kw = dict(puzzle_ids=ids, max_steps=200, pixels_per_cell=3, border_width=1, observation="uint8", device=0, autoreset=True)
     whole = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, **kw)
-    monkeypatch.setenv("PUSHWORLD_AMD_PAGE_SLICE_ENVS", "333")
-    sliced = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, **kw)
+    sliced = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, engine_options={"page_slice_envs": 333}, **kw)
     assert torch.equal(whole.reset(), sliced.reset())
     gen = torch.Generator(device=whole.device).manual_seed(12)
     for t in range(10):
@@ -260,12 +257,11 @@ def test_page_render_in_slices(golden, torch_mod, monkeypatch):
 
 @pytest.mark.parametrize("force_fused", ["1", "0"])
 def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_fused, monkeypatch):
-    """pw_step_render on a mixed batch, both schedules (PUSHWORLD_AMD_FUSED=1: ONE launch, step in
+    """pw_step_render on a mixed batch, both schedules (engine option fused_step_render = 1: ONE launch, step in
     wave 0 + per-environment render; 0: step kernel + page-ordered render): states, rewards,
     flags equal the golden trajectories and the observation equals the oracle's image of the
     reference state at every checked step (uint8, ppc 3, frame = batch maximum)."""
     torch = torch_mod
-    monkeypatch.setenv("PUSHWORLD_AMD_FUSED", force_fused)
     from oracle import c_oracle
     from pushworld_amd.vec_env import VecPushWorld
 
@@ -279,7 +275,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
     B = len(envs)
     T = 120
     vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=None, pixels_per_cell=3, border_width=1,
-                       observation="uint8", device=0, fused=True)
+                       observation="uint8", device=0, fused=True, engine_options={"fused_step_render": int(force_fused)})
     obs0 = vec.reset()
     oracles = {k: c_oracle.COraclePuzzle(golden.text(k)) for k in keys}
     fh, fw = vec.engine.obs_shape[0] // 3, vec.engine.obs_shape[1] // 3
@@ -315,7 +311,6 @@ def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, ke
     reward / terminated / truncated, on a mixed batch, with and without next-step autoreset; the
     per-step history of the plan sequences also equals the golden rewards of the reference."""
     torch = torch_mod
-    monkeypatch.setenv("PUSHWORLD_AMD_STEP", kernel)
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = [k for k in golden.keys if k.startswith(("bench:", "pytest:"))]
@@ -333,8 +328,11 @@ def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, ke
         actions[n:, b] = (np.arange(T - n) + b) % 4
     acts = torch.as_tensor(actions).to("cuda:0")
     ids = [e[0] for e in envs]
-    a = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset)
-    b_ = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset)
+    opts = {"step_kernel": kernel}
+    a = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset,
+                     engine_options=opts)
+    b_ = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset,
+                      engine_options=opts)
     a.reset()
     b_.reset()
     rh, th, uh = a.rollout(acts, history=True)

@@ -49,10 +49,7 @@ def test_bfs_numbering_equals_sequential_search(golden, chunk, monkeypatch):
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
 
-    if chunk:
-        monkeypatch.setenv("PUSHWORLD_AMD_SEARCH_CHUNK", chunk)
-    else:
-        monkeypatch.delenv("PUSHWORLD_AMD_SEARCH_CHUNK", raising=False)
+    chunk_arg = int(chunk) if chunk else None
     cap = 3000 if chunk else 60000
     n_checked = 0
     for key in CASES:
@@ -64,7 +61,7 @@ def test_bfs_numbering_equals_sequential_search(golden, chunk, monkeypatch):
         if len(want_states) > cap:
             continue  # space larger than the cap: covered by the truncated test below
         pz = PushWorldPuzzle(text=text)
-        bfs = BreadthFirstSearch(pz, max_states=cap + 8)
+        bfs = BreadthFirstSearch(pz, max_states=cap + 8, chunk=chunk_arg)
         bfs.begin()
         while not bfs.exhausted:
             bfs.expand()
@@ -281,10 +278,7 @@ def test_width_limited_search_equals_host_model(golden, width, chunk, monkeypatc
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
 
-    if chunk:
-        monkeypatch.setenv("PUSHWORLD_AMD_SEARCH_CHUNK", chunk)
-    else:
-        monkeypatch.delenv("PUSHWORLD_AMD_SEARCH_CHUNK", raising=False)
+    chunk_arg = int(chunk) if chunk else None
     keys = CASES + ["bench:level1/2 Obstacle.pwp", "bench:level1/Choose Wisely.pwp", "bench:level2/Pull Dont Push.pwp",
                     "cpptest:file_parsing.pwp", "bench:level2/Clean Sweep.pwp"]
     n_checked = n_pruned = n_solved = 0
@@ -298,7 +292,7 @@ def test_width_limited_search_equals_host_model(golden, width, chunk, monkeypatc
         if len(states) > cap:
             continue
         pz = PushWorldPuzzle(text=text)
-        bfs = BreadthFirstSearch(pz, max_states=cap + 8, novelty_width=width)
+        bfs = BreadthFirstSearch(pz, max_states=cap + 8, novelty_width=width, chunk=chunk_arg)
         bfs.begin()
         while not bfs.exhausted:
             bfs.expand()

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
-    assert lib.pw_abi_version() == 1
+    assert lib.pw_abi_version() == 2
 
 
 def test_parse_products_match_reference(golden):
@@ -236,6 +236,52 @@ def test_packed_set_file_round_trip_and_rejects_corruption(golden, tmp_path):
     for byte in evil[64:]:
         h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     assert struct.pack("<Q", h) == raw[40:48]
+
+    # Crafted files with a RECOMPUTED checksum: every index the kernels use unchecked is validated on load
+    # (section extents, object table, positions, movable-cell list), not only the section start offsets.
+    def crafted(patch):
+        data = bytearray(raw)
+        patch(data)
+        hh = 0xCBF29CE484222325
+        for byte in data[64:]:
+            hh = ((hh ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        data[40:48] = struct.pack("<Q", hh)
+        return bytes(data)
+
+    H0 = 64                      # PwPuzzleHeader of puzzle 0 (csrc/pw_format.h)
+    blob0 = 64 + 320 * len(keys)
+    base0, = struct.unpack_from("<I", raw, H0)
+    W0, Hh0, N0, G0 = raw[H0 + 4:H0 + 8]
+    off_static0, off_mcells0, n_mcells0 = struct.unpack_from("<III", raw, H0 + 20)
+    assert n_mcells0 >= 1 and N0 >= 1
+    blob_len = len(pset.blob())
+
+    def put(off, fmt, *vals):
+        return lambda d: struct.pack_into(fmt, d, off, *vals)
+
+    cases = {
+        "static section extent": put(H0 + 20, "<I", blob_len - base0 - 8),          # start inside, end outside
+        "movable-cell list extent": put(H0 + 28, "<I", 4000),                        # n_mcells * 4 beyond the blob
+        "shape row offset": put(H0 + 64 + 2, "<H", 60000),                           # objtab[0].row_off
+        "object height": put(H0 + 64 + 1, "<B", 65),                                 # objtab[0].h > 64
+        "object width": put(H0 + 64 + 0, "<B", W0 + 1),                              # objtab[0].w > W
+        "initial position": put(H0 + 256, "<b", W0),                                 # init[0].x outside the grid
+        "negative initial position": put(H0 + 256 + 1, "<b", -3),
+        "movable cell object index": put(blob0 + base0 + off_mcells0 + 3, "<B", N0),  # mcells[0].obj >= N
+        "movable cell x": put(blob0 + base0 + off_mcells0, "<B", 200),               # mcells[0].cx >= w
+        "static cell kind": put(blob0 + base0 + off_static0 + 1, "<B", 0x0F),        # kind 15
+        "goal count": put(H0 + 7, "<B", N0),                                         # G >= N
+        "zero width": put(H0 + 4, "<B", 0),
+    }
+    for what, patch in cases.items():
+        data = crafted(patch)
+        bad = str(tmp_path / "crafted.pwset")
+        with open(bad, "wb") as f:
+            f.write(data)
+        with pytest.raises(ValueError):
+            _capi.PuzzleSet.load(bad, -1)
+            pytest.fail(f"crafted file accepted: {what}")
+    assert crafted(lambda d: None) == raw   # the helper reproduces the genuine checksum
 
 
 def test_parser_fuzz_vectors_from_the_reference():

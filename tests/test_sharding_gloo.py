@@ -22,7 +22,8 @@ def _worker(rank, world, port, total, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
-    from pushworld_amd.sharding import reduce_counters, shard_bounds, shard_puzzle_ids
+    from pushworld_amd.sharding import (c4_global_puzzle_ids, gather_floats, reduce_counters, reduce_max, shard_bounds,
+                                        shard_puzzle_ids)
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -32,9 +33,17 @@ def _worker(rank, world, port, total, out_dir):
     lo, hi = shard_bounds(total, rank, world)
     counters = {"env_steps": (hi - lo) * 10, "episodes": rank + 1, "first_id": int(mine[0]) if len(mine) else 0}
     summed, elapsed = reduce_counters(counters, 0.5 + rank)
+    # bench.py's per-window MAX over ranks and per-rank report
+    wmax = reduce_max([1.0 + rank, 5.0 - rank])
+    per_rank = gather_floats(10.0 * (rank + 1))
+    # config C4: every rank derives the same global assignment and keeps its own slice
+    glob = c4_global_puzzle_ids(total, 14000, 223, 100)
+    c4_mine = np.sort(shard_puzzle_ids(glob, rank, world))
     dist.barrier()
     np.save(os.path.join(out_dir, f"r{rank}.npy"),
-            np.array([summed["env_steps"], summed["episodes"], elapsed, lo, hi, len(mine)], dtype=np.float64))
+            np.array([summed["env_steps"], summed["episodes"], elapsed, lo, hi, len(mine), wmax[0], wmax[1],
+                      per_rank[0], per_rank[1], float(glob.sum()), float(c4_mine.sum()), float(len(c4_mine)),
+                      float((c4_mine < 14000).sum())], dtype=np.float64))
     dist.destroy_process_group()
 
 
@@ -47,6 +56,13 @@ def test_two_rank_gloo_sharding(tmp_path, total):
         assert row[0] == total * 10 and row[1] == 3 and row[2] == 1.5  # SUM, SUM, MAX over ranks
     assert rows[0][3] == 0 and rows[0][4] == rows[1][3] and rows[1][4] == total  # contiguous cover
     assert abs(rows[0][5] - rows[1][5]) <= 1
+    for row in rows:
+        assert row[6] == 2.0 and row[7] == 5.0                 # element-wise MAX over ranks
+        assert row[8] == 10.0 and row[9] == 20.0               # gathered in rank order
+    assert rows[0][10] == rows[1][10]                           # same global C4 assignment on both ranks
+    assert rows[0][11] + rows[1][11] == rows[0][10] and rows[0][12] + rows[1][12] == total  # the shards partition it
+    for row in rows:
+        assert abs(row[13] / row[12] - 0.5) < 0.01              # 50 % Level 0 inside every shard
 
 
 def test_shard_bounds_cover_everything():
@@ -60,3 +76,29 @@ def test_shard_bounds_cover_everything():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert reduce_counters({"a": 3}, 2.0) == ({"a": 3}, 2.0)  # no process group: identity
+
+
+def test_c4_assignment_is_rank_independent_and_balanced():
+    from pushworld_amd.sharding import c4_global_puzzle_ids, gather_floats, reduce_max, shard_puzzle_ids
+
+    g = c4_global_puzzle_ids(524288, 14000, 223, 100)
+    assert g.shape == (524288,) and (g[0::2] < 14000).all() and (g[1::2] >= 14000).all() and g.max() < 14223
+    assert (g == c4_global_puzzle_ids(524288, 14000, 223, 100)).all()
+    assert len(np.unique(g[0::2])) == 14000 and len(np.unique(g[1::2])) == 223   # every puzzle of the mix is used
+    parts = [shard_puzzle_ids(g, r, 8) for r in range(8)]
+    assert all(len(p) == 65536 for p in parts) and (np.concatenate(parts) == g).all()
+    assert reduce_max([1.0, 2.0]) == [1.0, 2.0] and gather_floats(3.0) == [3.0]
+    with pytest.raises(ValueError):
+        c4_global_puzzle_ids(10, 0, 223)
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """No GPU here: ``bench.py --gpus 8`` must exit non-zero and print no result line (it used to run one rank and
+    report n_gpus 1)."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2"],
+                          capture_output=True, text=True, env=env, timeout=300)
+    assert proc.returncode != 0
+    assert '"metric"' not in proc.stdout
