@@ -43,6 +43,14 @@ def lib():
         l.or_rollout.restype = c_uint64
         l.or_rollout.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_int, c_int, POINTER(c_uint8), c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]
+        l.or_rollout_trace.restype = None
+        l.or_rollout_trace.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_int, c_int, POINTER(c_uint8), c_int, c_int,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        l.or_observe_batch.restype = None
+        l.or_observe_batch.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_void_p, c_int, POINTER(c_int32), c_int,
+                                       c_int, c_int, c_int, c_int, c_int, c_void_p]
+        l.or_expand4_batch.restype = None
+        l.or_expand4_batch.argtypes = [c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]
         _lib = l
     return _lib
 
@@ -130,6 +138,50 @@ class COraclePuzzle:
             lib().or_observation_u8(self.handle, ptr, max_cell_height, max_cell_width, ppc, border_width,
                                     out.ctypes.data, scratch.ctypes.data)
         return out
+
+
+def rollout_trace(puzzles, puzzle_ids, actions, max_steps, autoreset, np_pad):
+    """Every step of every environment (OpenMP over environments), from the initial states: returns
+    ``pos int8 [T, B, np_pad, 2], reward f64 [T, B], terminated u8 [T, B], truncated u8 [T, B], steps i32 [T, B]``
+    with next-step autoreset as in ``pw_step(PW_STEP_AUTORESET)`` when ``autoreset``."""
+    handles = (c_void_p * len(puzzles))(*[p.handle for p in puzzles])
+    pid = np.ascontiguousarray(np.asarray(puzzle_ids, dtype=np.int32))
+    acts = np.ascontiguousarray(np.asarray(actions, dtype=np.uint8))
+    T, B = acts.shape
+    pos = np.zeros((T, B, np_pad, 2), np.int8)
+    reward = np.zeros((T, B), np.float64)
+    term = np.zeros((T, B), np.uint8)
+    trunc = np.zeros((T, B), np.uint8)
+    steps = np.zeros((T, B), np.int32)
+    lib().or_rollout_trace(handles, pid.ctypes.data_as(POINTER(c_int32)), B, T, acts.ctypes.data_as(POINTER(c_uint8)),
+                           int(-1 if max_steps is None else max_steps), int(bool(autoreset)), int(np_pad),
+                           pos.ctypes.data, reward.ctypes.data, term.ctypes.data, trunc.ctypes.data, steps.ctypes.data)
+    return pos, reward, term, trunc, steps
+
+
+def observe_batch(puzzles, puzzle_ids, pos, sel, pad_h, pad_w, ppc, bw, dtype="u8"):
+    """Padded observations of the environments ``sel`` of a batch with positions ``pos`` int8 [B, NP, 2]."""
+    handles = (c_void_p * len(puzzles))(*[p.handle for p in puzzles])
+    pid = np.ascontiguousarray(np.asarray(puzzle_ids, dtype=np.int32))
+    pos = np.ascontiguousarray(np.asarray(pos, dtype=np.int8))
+    sel = np.ascontiguousarray(np.asarray(sel, dtype=np.int32))
+    out = np.zeros((len(sel), pad_h * ppc, pad_w * ppc, 3), np.float32 if dtype == "f32" else np.uint8)
+    lib().or_observe_batch(handles, pid.ctypes.data_as(POINTER(c_int32)), pos.ctypes.data, pos.shape[1],
+                           sel.ctypes.data_as(POINTER(c_int32)), len(sel), pad_h, pad_w, ppc, bw, int(dtype == "f32"),
+                           out.ctypes.data)
+    return out
+
+
+def expand4_batch(puzzle, states):
+    """``states`` int32 [F, N] Position2D -> (succ int32 [F, 4, N], moved uint32 [F, 4], goal uint8 [F, 4])."""
+    states = np.ascontiguousarray(np.asarray(states, dtype=np.int32))
+    F, N = states.shape
+    assert N == puzzle.num_movables
+    succ = np.zeros((F, 4, N), np.int32)
+    moved = np.zeros((F, 4), np.uint32)
+    goal = np.zeros((F, 4), np.uint8)
+    lib().or_expand4_batch(puzzle.handle, states.ctypes.data, F, succ.ctypes.data, moved.ctypes.data, goal.ctypes.data)
+    return succ, moved, goal
 
 
 def rollout(puzzles, puzzle_ids, actions, max_steps, render, pad_h, pad_w, ppc, bw, threads=0):

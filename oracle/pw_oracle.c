@@ -391,3 +391,97 @@ uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, 
   }
   return total;
 }
+
+/* ------------------------------------------------------------------ batched checkers for the full-size tests
+ * (tests/test_gpu_configs.py, tests/test_gpu_expand.py): the same per-environment calls as above, OpenMP over
+ * environments / states, every step's outputs kept. */
+
+/* T steps of B environments from their initial states.  autoreset != 0: next-step autoreset exactly as
+ * pw_step(PW_STEP_AUTORESET) -- an environment whose terminated | truncated flag is set on entry is reset
+ * instead of stepped (reward 0, flags 0, step counter 0).  Outputs per step: pos int8 [T][B][np][2] (zero
+ * beyond the puzzle's movables), reward f64 [T][B], terminated / truncated uint8 [T][B], steps int32 [T][B]. */
+void or_rollout_trace(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, const uint8_t* actions, int max_steps,
+                      int autoreset, int np, int8_t* pos, double* reward, uint8_t* term, uint8_t* trunc, int32_t* steps) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int b = 0; b < B; b++) {
+    const OrPuzzle* p = puzzles[pid[b]];
+    int state[2 * MAXN];
+    for (int j = 0; j < p->N; j++) {
+      state[2 * j] = p->init[j][0];
+      state[2 * j + 1] = p->init[j][1];
+    }
+    int n = 0, te = 0, tr = 0;
+    for (int t = 0; t < T; t++) {
+      double r = 0.0;
+      if (autoreset && (te | tr)) {
+        for (int j = 0; j < p->N; j++) {
+          state[2 * j] = p->init[j][0];
+          state[2 * j + 1] = p->init[j][1];
+        }
+        n = 0;
+        te = 0;
+        tr = 0;
+      } else {
+        te = or_env_step(p, state, actions[(size_t)t * B + b] & 3, &r);
+        n++;
+        tr = (max_steps >= 0 && n >= max_steps) ? 1 : 0;
+      }
+      const size_t o = (size_t)t * B + b;
+      int8_t* row = pos + o * np * 2;
+      for (int j = 0; j < np; j++) {
+        row[2 * j] = j < p->N ? (int8_t)state[2 * j] : 0;
+        row[2 * j + 1] = j < p->N ? (int8_t)state[2 * j + 1] : 0;
+      }
+      reward[o] = r;
+      term[o] = (uint8_t)te;
+      trunc[o] = (uint8_t)tr;
+      steps[o] = n;
+    }
+  }
+}
+
+/* Padded observations (uint8, or float32 when f32 != 0) of the K environments sel[0..K-1] of a batch whose
+ * positions are pos int8 [B][np][2]; out is [K][pad_h * ppc][pad_w * ppc][3]. */
+void or_observe_batch(OrPuzzle* const* puzzles, const int32_t* pid, const int8_t* pos, int np, const int32_t* sel, int K,
+                      int pad_h, int pad_w, int ppc, int bw, int f32, void* out) {
+  const size_t elems = (size_t)pad_h * ppc * pad_w * ppc * 3;
+#pragma omp parallel
+  {
+    uint8_t* scratch = (uint8_t*)malloc(elems);
+#pragma omp for schedule(dynamic, 4)
+    for (int k = 0; k < K; k++) {
+      const int b = sel[k];
+      const OrPuzzle* p = puzzles[pid[b]];
+      int state[2 * MAXN];
+      for (int j = 0; j < p->N; j++) {
+        state[2 * j] = pos[((size_t)b * np + j) * 2];
+        state[2 * j + 1] = pos[((size_t)b * np + j) * 2 + 1];
+      }
+      if (f32) or_observation_f32(p, state, pad_h, pad_w, ppc, bw, (float*)out + (size_t)k * elems, scratch);
+      else or_observation_u8(p, state, pad_h, pad_w, ppc, bw, (uint8_t*)out + (size_t)k * elems, scratch);
+    }
+    free(scratch);
+  }
+}
+
+/* The four successors of F states of one puzzle in the planner's wire format (pushworld_puzzle.h:32-37,
+ * Position2D = x * 10000 + y): succ int32 [F][4][N], moved uint32 [F][4] (bit k = object k moved,
+ * pushworld_puzzle.cc:446-457), goal uint8 [F][4] (satisfiesGoal of the successor, cc:462-469). */
+void or_expand4_batch(const OrPuzzle* p, const int32_t* states, int64_t F, int32_t* succ, uint32_t* moved, uint8_t* goal) {
+  const int N = p->N;
+#pragma omp parallel for schedule(static, 1024)
+  for (int64_t f = 0; f < F; f++) {
+    for (int a = 0; a < 4; a++) {
+      int state[2 * MAXN];
+      for (int j = 0; j < N; j++) {
+        state[2 * j] = states[f * N + j] / 10000;
+        state[2 * j + 1] = states[f * N + j] % 10000;
+      }
+      const uint32_t m = or_step(p, state, a);
+      const int64_t o = f * 4 + a;
+      for (int j = 0; j < N; j++) succ[o * N + j] = state[2 * j] * 10000 + state[2 * j + 1];
+      moved[o] = m;
+      goal[o] = (uint8_t)(or_count_goals(p, state) == p->G);
+    }
+  }
+}

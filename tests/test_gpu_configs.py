@@ -332,3 +332,110 @@ def test_batch_beyond_2_31_chunks():
     assert int(pad.max()) == 0
     del big, ob
     torch.cuda.empty_cache()
+
+
+def _compare_all_envs(vec, oracles, ids, acts, max_steps, frame, n_obs, obs_steps):
+    """Every environment, every step: positions, float64 reward bits, terminated, truncated, step counter
+    against the C oracle's trace (OpenMP over environments, next-step autoreset); full observations of
+    ``n_obs`` environments spread over the batch at the steps ``obs_steps``."""
+    import torch
+
+    from oracle import c_oracle
+
+    T, B = acts.shape
+    NP = vec.num_objects_padded
+    want_pos, want_r, want_te, want_tr, want_steps = c_oracle.rollout_trace(oracles, ids, acts, max_steps, True, NP)
+    acts_dev = torch.as_tensor(acts).to(vec.device)
+    sel = np.unique(np.linspace(0, B - 1, n_obs).astype(np.int64))
+    assert vec.reset() is not None
+    resets = 0
+    for t in range(T):
+        obs, r, te, tr = vec.step(acts_dev[t])
+        pos = vec.pos.cpu().numpy()
+        bad = np.nonzero((pos != want_pos[t]).any(axis=(1, 2)))[0]
+        assert bad.size == 0, (t, bad[:5], pos[bad[:1]], want_pos[t][bad[:1]])
+        assert (r.cpu().numpy().view(np.uint64) == want_r[t].view(np.uint64)).all(), t
+        assert (te.cpu().numpy() == want_te[t]).all() and (tr.cpu().numpy() == want_tr[t]).all(), t
+        assert (vec.steps.cpu().numpy() == want_steps[t]).all(), t
+        resets += int((want_steps[t] == 0).sum())
+        if t in obs_steps:
+            got = obs[torch.as_tensor(sel).to(vec.device)].cpu().numpy()
+            want = c_oracle.observe_batch(oracles, ids, want_pos[t], sel, frame[0], frame[1], 3, 1)
+            diff = np.nonzero((got != want).any(axis=(1, 2, 3)))[0]
+            assert diff.size == 0, (t, sel[diff[:5]])
+    return resets, len(sel)
+
+
+def test_c3_every_environment_against_the_oracle():
+    """C3 at full size: ALL 65 536 environments, 10 steps with max_steps 6 (so thousands of next-step autoresets
+    happen inside the window): state, float64 reward, flags and step counter of every environment at every step
+    equal the C oracle's; 1 024 complete observations (uint8 ppc 3, frame 51 x 42) at three of the steps."""
+    import bench
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    texts = [open(p).read() for p in paths]
+    B, T, max_steps = 65536, 10, 6
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    vec = VecPushWorld([PushWorldPuzzle(text=t) for t in texts], B, puzzle_ids=ids, max_steps=max_steps,
+                       pixels_per_cell=3, border_width=1, observation="uint8", device=0, autoreset=True, fused=True)
+    assert vec.engine.obs_shape == (153, 126, 3) and vec.engine.render_kernel == "pw_render_page_kernel"
+    oracles = [c_oracle.COraclePuzzle(t) for t in texts]
+    acts = np.random.default_rng(3).integers(0, 4, size=(T, B), dtype=np.uint8)
+    resets, n_obs = _compare_all_envs(vec, oracles, ids, acts, max_steps, (51, 42), 1024, (0, 6, T - 1))
+    assert resets >= B and n_obs >= 1000   # every environment was truncated and reset at least once
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_c4_shard_with_the_full_level0_pool_against_the_oracle(rank):
+    """C4 as specified: the rank's 65 536-environment shard of the 524 288-environment assignment
+    over ALL 14 000 Level-0 train puzzles + the 223 puzzles of Levels 1-4 (N_pad 32, frame 54 x 47), built the
+    way ``bench.py --config c4`` builds it: every environment at every step against the C oracle, and 1 024
+    complete uint8 ppc-3 observations."""
+    from oracle import c_oracle
+    from pushworld_amd import _capi
+    from pushworld_amd import benchmark_data as bd
+    from pushworld_amd.sharding import c4_global_puzzle_ids, shard_puzzle_ids
+    from pushworld_amd.vec_env import VecPushWorld
+
+    texts = list(bd.level0_texts().values())
+    n_l0 = len(texts)
+    for lv in (1, 2, 3, 4):
+        for p in bd.level_paths(lv):
+            with open(p) as f:
+                texts.append(f.read())
+    assert n_l0 == 14000 and len(texts) == 14223
+    B, T, max_steps = 65536, 9, 5
+    ids = np.sort(shard_puzzle_ids(c4_global_puzzle_ids(8 * B, n_l0, len(texts) - n_l0, 100), rank, 8))
+    pset = _capi.PuzzleSet([_capi.ParsedPuzzle(t) for t in texts], 0)
+    vec = VecPushWorld(pset, B, puzzle_ids=ids, max_steps=max_steps, pixels_per_cell=3, border_width=1,
+                       observation="uint8", pad_cells=(54, 47), device=0, autoreset=True, fused=True)
+    assert vec.num_objects_padded == 32 and vec.engine.obs_shape == (162, 141, 3)
+    used = np.unique(ids)
+    remap = np.full(len(texts), -1, np.int64)
+    remap[used] = np.arange(len(used))
+    oracles = [c_oracle.COraclePuzzle(texts[int(p)]) for p in used]
+    acts = np.random.default_rng(100 + rank).integers(0, 4, size=(T, B), dtype=np.uint8)
+    # the oracle sees a compacted pool (only the puzzles of this shard), the engine the full one
+    import torch
+    T_, B_ = acts.shape
+    want = c_oracle.rollout_trace(oracles, remap[ids], acts, max_steps, True, 32)
+    acts_dev = torch.as_tensor(acts).to(vec.device)
+    sel = np.unique(np.linspace(0, B - 1, 1024).astype(np.int64))
+    vec.reset()
+    for t in range(T):
+        obs, r, te, tr = vec.step(acts_dev[t])
+        pos = vec.pos.cpu().numpy()
+        bad = np.nonzero((pos != want[0][t]).any(axis=(1, 2)))[0]
+        assert bad.size == 0, (t, bad[:5])
+        assert (r.cpu().numpy().view(np.uint64) == want[1][t].view(np.uint64)).all(), t
+        assert (te.cpu().numpy() == want[2][t]).all() and (tr.cpu().numpy() == want[3][t]).all(), t
+        assert (vec.steps.cpu().numpy() == want[4][t]).all(), t
+        if t in (0, 5, T - 1):
+            got = obs[torch.as_tensor(sel).to(vec.device)].cpu().numpy()
+            ref = c_oracle.observe_batch(oracles, remap[ids], want[0][t], sel, 54, 47, 3, 1)
+            diff = np.nonzero((got != ref).any(axis=(1, 2, 3)))[0]
+            assert diff.size == 0, (t, sel[diff[:5]])
+    assert (want[4] == 0).sum() >= B

@@ -144,3 +144,41 @@ def test_expand_large_frontier_consistency(golden):
         got = vec.states()[:, :n].astype(np.int32)
         assert (got[:, :, 0] * 10000 + got[:, :, 1] == succ[:, a]).all()
         assert (term.cpu().numpy() == goal[:, a].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("key", ["bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp",
+                                 "bench:level4/Four Pistons.pwp"])
+def test_million_state_frontier_against_the_oracle(golden, key):
+    """C5 at the size BASELINE.json names: >= 1 M distinct reachable states (all of them if the puzzle has fewer)
+    in the C++ object order, collected by the GPU breadth-first search; pw_expand4's four successors, moved masks
+    (= moved_object_indices, pushworld_puzzle.cc:446-457) and goal flags of EVERY state equal the C oracle's
+    (tables + LIFO frontier, OpenMP over states)."""
+    import torch
+
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.search import BreadthFirstSearch
+
+    text = golden.text(key)
+    pz = PushWorldPuzzle(text=text, order="cpp")
+    oz = c_oracle.COraclePuzzle(text, order="cpp")
+    target = 1_000_000
+    bfs_gpu = BreadthFirstSearch(pz, max_states=6_000_000)
+    bfs_gpu.begin()
+    while bfs_gpu.total_states < target and not bfs_gpu.exhausted:
+        bfs_gpu.expand()
+    F = bfs_gpu.total_states
+    assert F >= target or bfs_gpu.exhausted
+    xy = bfs_gpu.states(0, F)
+    bfs_gpu.close()
+    states = (xy[:, :, 0].astype(np.int64) * 10000 + xy[:, :, 1]).astype(np.int32)
+    assert len(np.unique(states, axis=0)) == F          # the search's closed set: all distinct
+    succ, moved, goal = pz.expand4(states)
+    want_succ, want_moved, want_goal = c_oracle.expand4_batch(oz, states)
+    got_succ = succ.cpu().numpy()
+    bad = np.nonzero((got_succ != want_succ).any(axis=(1, 2)))[0]
+    assert bad.size == 0, (key, bad[:5])
+    assert (moved.cpu().numpy().astype(np.uint32) == want_moved).all()
+    assert (goal.cpu().numpy() == want_goal).all()
+    # the layers the search itself produced are closed under expansion up to the last complete layer
+    assert want_moved.any() and got_succ.shape == (F, 4, pz.num_movables)

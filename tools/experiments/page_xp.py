@@ -3,9 +3,13 @@
 process on the same buffers (box-to-box and allocation-to-allocation spread exceeds most effects):
 
     bits 0..2  rotation of the page index inside groups of 8 consecutive pages (which XCD writes which page)
-    bits 3..4  page order: 0 address order, 1 one contiguous eighth of the buffer per XCD
-    bit  5     plain instead of non-temporal stores
+    bits 3..4  page order: 0 address order, 1 one contiguous eighth of the buffer per XCD, 2 every XCD writes runs
+               of 2^(bits 24..28) consecutive pages (the chip-wide front stays 8 runs wide), 3 as 1 with XCD k starting
+               k * (bits 32..47) pages into its eighth
+    bits 20..22 cache policy of the observation stores (compile-time variants of the production kernel):
+               0 nt (production), 1 plain, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt, 6 sc0 nt, 7 sc0
     bits 8..15 KiB of dynamic LDS per workgroup (occupancy limit)
+    bit  7     no-op (selects the experiment build of the kernel with default behaviour)
     bit  16    per-environment page records (one scalar load on the fast path)
 
 Every variant's output is compared byte for byte with the default's.  Usage: page_xp.py [--allocs N] [--reps R]"""
@@ -62,11 +66,19 @@ def main():
     eng.set_option("experiment", 0)
     render_into(ref)
     torch.cuda.synchronize()
-    variants = [("default", 0)]
+    variants = [("default", 0), ("xp-kernel-noop", 0x80), ("default-again", 0)]
     variants += [(f"rot{r}", r) for r in range(1, 8)]
-    variants += [("xcd-chunks", 1 << 3), ("plain-stores", 1 << 5)]
-    variants += [(f"lds{k}K", k << 8) for k in (4, 8, 16, 32)]
-    variants += [("records", 1 << 16), ("records+plain", (1 << 16) | (1 << 5)), ("records+lds8K", (1 << 16) | (8 << 8))]
+    variants = [("default", 0), ("xcd-chunks", 1 << 3), ("runs of 64", (2 << 3) | (6 << 24))]
+    variants += [(f"stagger {st}", (3 << 3) | (st << 32)) for st in (1, 3, 9, 33, 129, 585, 1171, 4097, 14464)]
+    variants += [(f"stagger {st}+lds4K", (3 << 3) | (st << 32) | (4 << 8)) for st in (9, 585, 14464)]
+    variants += [(f"stagger {st}+lds6K", (3 << 3) | (st << 32) | (6 << 8)) for st in (585,)]
+    variants += [(f"stagger {st}+rec", (3 << 3) | (st << 32) | (1 << 16)) for st in (585,)]
+    variants += [(f"lds{k}K", k << 8) for k in (5, 6, 7)]
+    variants += [("runs64+lds6K", (2 << 3) | (6 << 24) | (6 << 8)), ("runs128+lds6K", (2 << 3) | (7 << 24) | (6 << 8)),
+                 ("default-again", 0)]
+    names = ["nt", "plain", "sc1", "sc0 sc1", "sc1 nt", "sc0 sc1 nt", "sc0 nt", "sc0"]
+    if args.obs == "uint8":
+        variants += [("store:" + names[k], k << 20) for k in (4,)]
     bufs = [("engine", ref)]
     for i in range(args.allocs):
         bufs.append((f"fresh{i}", torch.zeros((B, stride // esz), dtype=ref.dtype, device=vec.device)))
