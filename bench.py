@@ -382,6 +382,11 @@ def main():
             "n_pad": n_obj,
             "parallelism": f"env-sharded x{world}, no data-path collective"
                            + (f" (counters over {backend})" if backend else ""),
+            # launch configuration of the page-ordered render kernel on rank 0 (pw_engine_tune_render at the first
+            # reset: same bytes, the fastest of 14 page orders / occupancies for THIS observation buffer)
+            "render_launch": {"tuned_index": vec.tuned_config, "page_order": eng.get_option("page_order"),
+                              "page_run_log2": eng.get_option("page_run_log2"),
+                              "page_lds_pad_kb": eng.get_option("page_lds_pad_kb")},
         },
         "timing": {
             "windows": M,

@@ -152,14 +152,28 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_PAGE_SLICE_ENVS 4   /* page kernels: environments per launch (0 = as many as 2^31 chunks allow) */
 #define PW_OPT_SEARCH_CHUNK 5      /* pw_search_create: parents per expansion pass (0 = 2^20) */
 #define PW_OPT_PROFILE_RENDER 6    /* n > 0: time the next n render launches with HIP events on their stream */
-#define PW_OPT_EXPERIMENT 7        /* bit field of A/B variants of the page-ordered render kernel (tools/experiments):
-                                      page order, store kind, occupancy limit, per-environment page records */
+/* launch configuration of the page-ordered render kernel (same bytes, different speed; see pw_engine_tune_render) */
+#define PW_OPT_PAGE_ORDER 7        /* which 4 KiB page a workgroup writes: 0 page = workgroup index, 1 every XCD sweeps
+                                      one contiguous eighth of the buffer, 2 every XCD writes runs of 2^RUN_LOG2 pages */
+#define PW_OPT_PAGE_RUN_LOG2 8     /* log2 of the run length of order 2 (default 6) */
+#define PW_OPT_PAGE_LDS_PAD_KB 9   /* KiB of unused dynamic LDS per workgroup: caps the workgroups per CU, i.e. the width
+                                      of the chip-wide write front (default 7 for uint8, 8 for float32 observations) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order
  * (PW_OPT_PROFILE_RENDER).  Waits for them to finish, writes at most `cap` values, returns how many
  * were recorded and starts over. */
 int pw_engine_profile_read(PwEngine* e, float* ms, int32_t cap);
+
+/* Auto-tuning of the page-ordered render kernel's launch configuration (PW_OPT_PAGE_*): which page order and
+ * occupancy is fastest depends on the physical backing of the observation buffer (measured: the same kernel
+ * takes 0.545 .. 0.66 ms on buffers of identical size and alignment).  Renders (puzzle_id, pos) into `obs` with
+ * every candidate configuration (a few launches each, HIP events on `stream`), keeps the fastest for this
+ * engine and returns its index (0 = the default).  `obs` holds the correct observations on return; the
+ * stream is synchronised.  Engines that do not use the page-ordered kernel just render.  Call once per
+ * observation buffer, e.g. right after allocating it. */
+int pw_engine_tune_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs,
+                          int64_t env_stride_bytes, int32_t batch, void* stream);
 
 /* Number of out-of-range actions (not in 0..3) the step kernels of this engine have seen since the
  * last call; reads and clears the counter, synchronises `stream`.  An asynchronous caller that never

@@ -122,6 +122,7 @@ SIGNATURES = {
     "pw_engine_set_option": (c_int, [c_void_p, c_int32, c_int64]),
     "pw_engine_get_option": (c_int64, [c_void_p, c_int32]),
     "pw_engine_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_float), c_int32]),
+    "pw_engine_tune_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_engine_bad_actions": (c_int64, [c_void_p, c_void_p]),
     "pw_validate_state": (c_int64, [c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
 }
@@ -134,7 +135,9 @@ OPTIONS = {
     "page_slice_envs": 4,
     "search_chunk": 5,
     "profile_render": 6,
-    "experiment": 7,
+    "page_order": 7,
+    "page_run_log2": 8,
+    "page_lds_pad_kb": 9,
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1}
 
@@ -369,6 +372,13 @@ class Engine:
         buf = (ctypes.c_float * max(cap, 1))()
         n = check(lib.pw_engine_profile_read(self.handle, buf, cap))
         return [buf[i] for i in range(min(n, cap))]
+
+    def tune_render(self, puzzle_id, pos, obs_storage) -> int:
+        """``pw_engine_tune_render``: times the launch configurations of the page-ordered render kernel on these
+        buffers, keeps the fastest (``page_order`` / ``page_run_log2`` / ``page_lds_pad_kb`` options) and returns
+        its index; ``obs_storage`` holds the observations of ``pos`` afterwards."""
+        return check(lib.pw_engine_tune_render(self.handle, _ptr(puzzle_id), _ptr(pos), _ptr(obs_storage),
+                                               self.obs_stride, pos.shape[0], self._stream()))
 
     def bad_actions(self) -> int:
         """Out-of-range actions seen by this engine's step kernels since the last call (reads and clears the

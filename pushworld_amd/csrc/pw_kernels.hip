@@ -54,7 +54,9 @@ struct PwEngine {
   bool force_lds_render;   // PW_OPT_RENDER_KERNEL = 1: per-environment LDS kernel even where the page kernel applies
   int64_t page_slice_envs; // PW_OPT_PAGE_SLICE_ENVS: environments per page-kernel launch (0 = what 2^31 chunks allow)
   int64_t search_chunk;    // PW_OPT_SEARCH_CHUNK: parents per pw_search_expand pass (0 = 2^20)
-  int64_t experiment;      // PW_OPT_EXPERIMENT: A/B variants of the page kernel (CopyArgs::xp), never a different result
+  // launch configuration of the page-ordered render kernel (CopyArgs::order / run_log2, dynamic LDS as an
+  // occupancy cap); defaults are the robust optimum, pw_engine_tune_render measures the caller's buffer
+  int page_order, page_run_log2, page_lds_pad_kb;
   void* d_rec;             // page records (PageRec [rec_cap]), grown on demand
   int64_t rec_cap;
   // PW_OPT_PROFILE_RENDER: HIP event pairs around the dominant (render) launch, on the launch stream
@@ -64,7 +66,8 @@ struct PwEngine {
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)
-  bool simg_cached;        // the static images of the whole set stay cache resident: page-ordered full render
+  bool simg_cached;        // the page-ordered full render applies: the bytes of the static images that are actually
+                           // read (everything but the frame padding rows) stay cache resident or nearly so
   int64_t simg_stride;     // bytes between the static images of consecutive puzzles
   uint16_t* d_estat;       // per puzzle: static zone-colour table in this engine's frame layout
   uint32_t* d_estat_off;   // byte offset of puzzle p's table in d_estat (16 B aligned)
@@ -218,6 +221,17 @@ __device__ __forceinline__ uint32_t push_closure(const PuzzleView& pv, const Env
   }
   return pushed;
 }
+
+// Per-environment record for the page kernel: everything the pages that no movable reaches need -- the puzzle
+// (-> static image), its size (-> position of the image inside the frame) and the grid rows covered by some
+// movable's bounding box.  16 bytes, fetched with ONE scalar load; written by the group step kernel
+// (pw_step_render) or by pw_page_records_kernel (pw_render).
+struct PageRec {
+  int32_t pid;
+  uint8_t H, W;
+  uint16_t reserved;
+  uint64_t rows;  // bit y: some movable's bounding box covers grid row y
+};
 
 #include "pw_step_kernels.inc"
 #include "pw_render_kernels.inc"

@@ -46,6 +46,9 @@ class VecPushWorld:
             Draws happen in ``reset`` (all / masked environments) and, with ``autoreset``, at the
             start of the ``step`` that resets a finished environment.
         seed: seed of the counter-based draw: puzzle = f(seed, environment index, episode number).
+        tune: auto-tune the launch configuration of the page-ordered render kernel on this environment's own
+            observation buffer at the first ``reset`` (``pw_engine_tune_render``, a few dozen extra render launches
+            once).  Default: on for observation buffers of 256 MB and more, where the choice is worth 5-15 %.
         engine_options: ``pw_engine_set_option`` settings (``_capi.OPTIONS``), e.g. ``{"step_kernel": "lane"}`` --
             kernel selection for tests and A/B runs; results never depend on them.
     """
@@ -55,7 +58,7 @@ class VecPushWorld:
                  border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
                  autoreset: bool = False, fused: bool = False, resample=False, seed: int = 0,
-                 incremental: bool = False, engine_options: Optional[dict] = None):
+                 incremental: bool = False, engine_options: Optional[dict] = None, tune: Optional[bool] = None):
         if observation not in ("uint8", "float32", None):
             raise ValueError("observation must be 'uint8', 'float32' or None")
         dev = default_device_index() if device is None else int(device)
@@ -98,6 +101,10 @@ class VecPushWorld:
         else:
             self._obs_storage, self.obs = None, None
         self._has_reset = False
+        if tune is None:
+            tune = self.obs is not None and self.num_envs * self.engine.obs_stride >= (256 << 20)
+        self._tune_pending = bool(tune) and self.obs is not None
+        self.tuned_config = None  # index returned by pw_engine_tune_render, once it ran
 
         self.seed = int(seed)
         self.resample = resample is not False and resample is not None
@@ -132,7 +139,11 @@ class VecPushWorld:
         self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, mask)
         self._has_reset = True
         if self.obs is not None:
-            self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+            if self._tune_pending:  # renders, too
+                self.tuned_config = self.engine.tune_render(self.puzzle_id, self.pos, self._obs_storage)
+                self._tune_pending = False
+            else:
+                self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
             self._obs_current = True
         return self.obs
 

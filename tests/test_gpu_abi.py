@@ -33,8 +33,10 @@ def test_engine_options_round_trip_and_select_kernels(torch_mod):
 
     vec = _level1_vec()
     eng = vec.engine
-    for name in _capi.OPTIONS:
+    for name in ("step_kernel", "fused_step_render", "render_kernel", "page_slice_envs", "search_chunk", "profile_render"):
         assert eng.get_option(name) == 0
+    # launch configuration of the page kernel: the robust default until the tuner has run
+    assert (eng.get_option("page_order"), eng.get_option("page_run_log2"), eng.get_option("page_lds_pad_kb")) == (2, 6, 7)
     assert eng.render_kernel == "pw_render_page_kernel"
     eng.set_option("render_kernel", "lds")
     assert eng.get_option("render_kernel") == 1 and eng.render_kernel == "pw_render_u8_ppc3_kernel"
@@ -43,7 +45,8 @@ def test_engine_options_round_trip_and_select_kernels(torch_mod):
     assert eng.get_option("step_kernel") == 2
     eng.set_option("page_slice_envs", 100)
     assert eng.get_option("page_slice_envs") == 100
-    for bad in (("step_kernel", 3), ("render_kernel", 2), ("page_slice_envs", -1), (99, 0)):
+    for bad in (("step_kernel", 3), ("render_kernel", 2), ("page_slice_envs", -1), ("page_order", 3), ("page_lds_pad_kb", 49),
+                (99, 0)):
         with pytest.raises(ValueError):
             eng.set_option(*bad)
     # options never change results: same walk with every combination

@@ -118,6 +118,43 @@ def test_cpp_known_answers():
     assert sorted(p for g in goal_states if depth[g] == best for p in plans[g]) == ["RDRU"]
 
 
+def test_cpp_hand_built_collision_cases():
+    """cpp/test/test_pushworld_puzzle.cc:84-257 on the HIP path: the reference's hand-built ObjectCollisions cases
+    (tests/cpp_cases.py) through pw_expand4 -- successor, moved_object_indices (as a bit mask) and satisfiesGoal."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpp_cases
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    n = 0
+    for name, text, steps in cpp_cases.movement_cases():
+        pz = PushWorldPuzzle(text=text, order="cpp")
+        assert tuple(pz.initial_state) == steps[0][0], name
+        states = np.array([p2d(st) for st, _, _, _ in steps], dtype=np.int32)
+        succ, moved, goal = pz.expand4(states)
+        succ, moved = succ.cpu().numpy(), moved.cpu().numpy().astype(np.uint32)
+        for i, (state, action, want, want_moved) in enumerate(steps):
+            assert succ[i, action].tolist() == p2d(want), (name, state, action)
+            if want_moved is not None:
+                assert int(moved[i, action]) == sum(1 << k for k in want_moved), (name, state, action)
+            assert pz.get_next_state(state, action) == want            # the single-state surface (pw_step)
+            n += 1
+    assert n == 22
+    for name, text, checks in cpp_cases.goal_cases():
+        pz = PushWorldPuzzle(text=text, order="cpp")
+        states = np.array([p2d(st) for st, _ in checks], dtype=np.int32)
+        succ, moved, goal = pz.expand4(states)
+        succ, moved, goal = succ.cpu().numpy(), moved.cpu().numpy().astype(np.uint32), goal.cpu().numpy()
+        for i, (state, want) in enumerate(checks):
+            # an action that moves at most the agent leaves the goal objects where the reference test put them:
+            # the successor's flag is satisfiesGoal of exactly those positions
+            quiet = [a for a in range(4) if int(moved[i, a]) in (0, 1)]
+            assert quiet, (name, state)
+            for a in quiet:
+                assert succ[i, a, 1:].tolist() == p2d(state[1:]) and bool(goal[i, a]) == want, (name, state, a)
+
+
 def test_expand_large_frontier_consistency(golden):
     """>= 100k states of 'level1/2 Obstacle': expand4 agrees with 4 single-action pw_step
     launches on the same states (two different kernels, same dynamics)."""

@@ -119,9 +119,10 @@ def test_incremental_generic_kernel_equals_full_render(golden, kw):
 
 
 def test_incremental_with_large_pool_static_images_in_hbm(golden):
-    """860 puzzles in a 64 x 64 frame: the static images (95 MB) are no longer cache resident, so the
-    full render takes the per-environment LDS kernel while the incremental path still patches from the
-    images; results stay identical, through autoreset with re-sampling."""
+    """860 puzzles of every size in a 64 x 64 frame: 95 MB of static images, of which the page-ordered kernel reads
+    only each puzzle's own pixel rows (the frame padding above and below is neither loaded nor computed).  The
+    page-ordered full render, the per-environment LDS kernel and the incremental path stay byte-identical, through
+    autoreset with re-sampling (environments of one puzzle no longer sit next to each other)."""
     import torch
     from pushworld_amd.vec_env import VecPushWorld
 
@@ -131,14 +132,16 @@ def test_incremental_with_large_pool_static_images_in_hbm(golden):
     kw = dict(puzzle_ids=ids, max_steps=17, pixels_per_cell=3, border_width=1, observation="uint8", pad_cells=(64, 64),
               autoreset=True, resample=True, seed=3)
     full = VecPushWorld(pool, B, **kw)
+    lds = VecPushWorld(pool, B, engine_options={"render_kernel": "lds"}, **kw)
     inc = VecPushWorld(pool, B, incremental=True, **kw)
-    assert full.engine.render_kernel == "pw_render_u8_ppc3_kernel"
+    assert full.engine.render_kernel == "pw_render_page_kernel" and lds.engine.render_kernel == "pw_render_u8_ppc3_kernel"
     g = torch.Generator(device=full.device).manual_seed(4)
-    assert torch.equal(full.reset(seed=3), inc.reset(seed=3))
+    first = full.reset(seed=3)
+    assert torch.equal(first, inc.reset(seed=3)) and torch.equal(first, lds.reset(seed=3))
     for t in range(T):
         a = torch.randint(0, 4, (B,), dtype=torch.uint8, device=full.device, generator=g)
-        fo, io = full.step(a), inc.step(a)
-        assert torch.equal(fo[0], io[0]), t
+        fo, lo, io = full.step(a), lds.step(a), inc.step(a)
+        assert torch.equal(fo[0], io[0]) and torch.equal(fo[0], lo[0]), t
         assert torch.equal(full.puzzle_id, inc.puzzle_id) and torch.equal(full.pos, inc.pos), t
 
 

@@ -192,8 +192,11 @@ def test_full_small_images(golden, puzzles, torch_mod):
         assert (img == want).all(), (key, np.argwhere(img != want)[:5])
 
 
+PAGE_CONFIGS = [None, (0, 0, 0), (1, 0, 0), (1, 0, 5), (2, 0, 0), (2, 3, 7), (2, 6, 0), (2, 11, 2), (2, 20, 9)]
+
+
 @pytest.mark.parametrize("obs_kind", ["uint8", "float32"])
-@pytest.mark.parametrize("path", ["page"])
+@pytest.mark.parametrize("path", PAGE_CONFIGS)
 def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monkeypatch):
     """The page-ordered render kernel (default for uint8 / ppc 3: static-image copy + LDS entry window)
     and the per-environment LDS kernel (engine option render_kernel = "lds") produce byte-identical observations
@@ -207,13 +210,15 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     B, T = 2048, 25
     ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
 
-    def make(kernel):
+    def make(opts):
         return VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, pixels_per_cell=3,
-                            border_width=1, observation=obs_kind, device=0, autoreset=True,
-                            engine_options={"render_kernel": kernel})
+                            border_width=1, observation=obs_kind, device=0, autoreset=True, engine_options=opts)
 
-    ref = make("lds")
-    alt = make(path)
+    # every launch configuration of the page kernel (page order, run length, occupancy padding; None = defaults)
+    # and both producers of its page records: the step kernel (fused=True -> pw_step_render) and the pre-pass
+    ref = make({"render_kernel": "lds"})
+    alt = make({} if path is None else dict(zip(("page_order", "page_run_log2", "page_lds_pad_kb"), path)))
+    alt.fused = path is None or path[0] != 1
     assert ref.engine.render_kernel != "pw_render_page_kernel" and alt.engine.render_kernel == "pw_render_page_kernel"
     o_ref, o_alt = ref.reset(), alt.reset()
     assert torch.equal(o_ref, o_alt)
@@ -230,6 +235,10 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     pos[:, 1:] = pos[:, :-1]
     for v in (ref, alt):
         v.set_states(pos)
+    assert torch.equal(ref.render(), alt.render())
+    # the tuner leaves correct observations behind and a configuration from its candidate list
+    idx = alt.engine.tune_render(alt.puzzle_id, alt.pos, alt._obs_storage)
+    assert 0 <= idx < 14 and torch.equal(alt._obs_storage, ref._obs_storage)
     assert torch.equal(ref.render(), alt.render())
 
 

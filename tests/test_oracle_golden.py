@@ -174,6 +174,37 @@ def test_cpp_order_known_answers(golden):
     assert [len(ov.static[a][0]) for a in range(4)] == [2, 2, 2, 2]
     assert [len(ov.dynamic[a][0][1]) for a in (L, R, U, D)] == [2, 2, 1, 1]
     assert [len(ov.dynamic[a][2][1]) for a in (L, R, U, D)] == [2, 2, 1, 1]
+    # the remaining literal expectations of cc:400-458: members of the agent's static sets, sizes for object 2
+    assert ov.static[L][0] == {(1, 1), (1, 2)} and ov.static[U][0] == {(1, 1), (2, 1)}
+    assert ov.static[R][0] == {(2, 1), (1, 2)} and ov.static[D][0] == {(2, 1), (1, 2)}
+    assert [len(ov.dynamic[a][0][2]) for a in (L, R, U, D)] == [1, 1, 1, 1]
+
+
+@pytest.mark.parametrize("impl", ["python", "c"])
+def test_cpp_hand_built_collision_cases(impl):
+    """cpp/test/test_pushworld_puzzle.cc:84-257 (agent movement with hand-set agent walls, pushing, transitive
+    pushing with moved_object_indices, satisfiesGoal), re-expressed as small puzzles: tests/cpp_cases.py."""
+    import cpp_cases
+
+    def make(text):
+        return c_oracle.COraclePuzzle(text, order="cpp") if impl == "c" else pw_oracle.OraclePuzzle(text, order="cpp")
+
+    n = 0
+    for name, text, steps in cpp_cases.movement_cases():
+        o = make(text)
+        assert tuple(o.initial_state) == steps[0][0], name
+        for state, action, want, moved in steps:
+            got, got_moved = o.get_next_state_moved(state, action)
+            assert got == want, (name, state, action)
+            if moved is not None:
+                assert list(got_moved) == moved, (name, state, action)   # agent first, ascending, empty if blocked
+            n += 1
+    assert n == 22
+    for name, text, checks in cpp_cases.goal_cases():
+        o = pw_oracle.OraclePuzzle(text, order="cpp")
+        assert o.initial_state == ((1, 1), (2, 2), (3, 3)), name
+        for state, want in checks:
+            assert o.is_goal_state(state) == want, (name, state)
 
 
 def test_python_and_cpp_orders_agree_up_to_permutation(golden):

@@ -1,18 +1,15 @@
 #!/usr/bin/env python3
-"""A/B of the page-ordered render kernel's experiment bits (PW_OPT_EXPERIMENT) on the C3 batch, all inside ONE
-process on the same buffers (box-to-box and allocation-to-allocation spread exceeds most effects):
+"""Launch configurations of the page-ordered render kernel on the C3 batch, all inside ONE process on several
+buffers of identical size (box-to-box and allocation-to-allocation spread exceeds most effects):
 
-    bits 0..2  rotation of the page index inside groups of 8 consecutive pages (which XCD writes which page)
-    bits 3..4  page order: 0 address order, 1 one contiguous eighth of the buffer per XCD, 2 every XCD writes runs
-               of 2^(bits 24..28) consecutive pages (the chip-wide front stays 8 runs wide), 3 as 1 with XCD k starting
-               k * (bits 32..47) pages into its eighth
-    bits 20..22 cache policy of the observation stores (compile-time variants of the production kernel):
-               0 nt (production), 1 plain, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt, 6 sc0 nt, 7 sc0
-    bits 8..15 KiB of dynamic LDS per workgroup (occupancy limit)
-    bit  7     no-op (selects the experiment build of the kernel with default behaviour)
-    bit  16    per-environment page records (one scalar load on the fast path)
+    page_order       0 page = workgroup index, 1 one contiguous eighth of the buffer per XCD, 2 runs of
+                     2^page_run_log2 pages per XCD
+    page_lds_pad_kb  KiB of unused dynamic LDS per workgroup (occupancy cap = width of the write front)
 
-Every variant's output is compared byte for byte with the default's.  Usage: page_xp.py [--allocs N] [--reps R]"""
+Every configuration's output is compared byte for byte with the first one's, and the engine's tuner
+(pw_engine_tune_render) is run on every buffer.  Usage: page_xp.py [--allocs N] [--reps R] [--obs uint8|float32]
+Earlier rounds of this experiment (store cache policies, page rotation, staggered eighths, page records) are
+summarised in profiles/r02_page_xp.txt."""
 import argparse
 import os
 import sys
@@ -31,14 +28,14 @@ from pushworld_amd.vec_env import VecPushWorld  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--allocs", type=int, default=3)
-    ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--obs", default="uint8")
     args = ap.parse_args()
     B = 65536
     paths = bench.level1_paths()
     ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
     vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, pixels_per_cell=3,
-                       border_width=1, observation=args.obs, autoreset=True)
+                       border_width=1, observation=args.obs, autoreset=True, tune=False)
     vec.reset()
     g = torch.Generator(device=vec.device).manual_seed(1)
     for _ in range(30):  # a typical mid-episode batch
@@ -50,8 +47,9 @@ def main():
         _capi.check(_capi.lib.pw_render(eng.handle, _capi._ptr(vec.puzzle_id), _capi._ptr(vec.pos), _capi._ptr(storage),
                                         stride, B, eng._stream()))
 
-    def timed(storage, xp, reps):
-        eng.set_option("experiment", xp)
+    def timed(storage, cfg, reps):
+        for k, v in zip(("page_order", "page_run_log2", "page_lds_pad_kb"), cfg):
+            eng.set_option(k, v)
         for _ in range(3):
             render_into(storage)
         eng.profile_render(reps)
@@ -63,36 +61,38 @@ def main():
 
     esz = 1 if args.obs == "uint8" else 4
     ref = vec._obs_storage
-    eng.set_option("experiment", 0)
+    default = tuple(eng.get_option(k) for k in ("page_order", "page_run_log2", "page_lds_pad_kb"))
     render_into(ref)
     torch.cuda.synchronize()
-    variants = [("default", 0), ("xp-kernel-noop", 0x80), ("default-again", 0)]
-    variants += [(f"rot{r}", r) for r in range(1, 8)]
-    variants = [("default", 0), ("xcd-chunks", 1 << 3), ("runs of 64", (2 << 3) | (6 << 24))]
-    variants += [(f"stagger {st}", (3 << 3) | (st << 32)) for st in (1, 3, 9, 33, 129, 585, 1171, 4097, 14464)]
-    variants += [(f"stagger {st}+lds4K", (3 << 3) | (st << 32) | (4 << 8)) for st in (9, 585, 14464)]
-    variants += [(f"stagger {st}+lds6K", (3 << 3) | (st << 32) | (6 << 8)) for st in (585,)]
-    variants += [(f"stagger {st}+rec", (3 << 3) | (st << 32) | (1 << 16)) for st in (585,)]
-    variants += [(f"lds{k}K", k << 8) for k in (5, 6, 7)]
-    variants += [("runs64+lds6K", (2 << 3) | (6 << 24) | (6 << 8)), ("runs128+lds6K", (2 << 3) | (7 << 24) | (6 << 8)),
-                 ("default-again", 0)]
-    names = ["nt", "plain", "sc1", "sc0 sc1", "sc1 nt", "sc0 sc1 nt", "sc0 nt", "sc0"]
-    if args.obs == "uint8":
-        variants += [("store:" + names[k], k << 20) for k in (4,)]
+    variants = [("default %s" % (default,), default), ("identity", (0, 0, 0)), ("eighths", (1, 0, 0))]
+    variants += [(f"runs64 pad{k}K", (2, 6, k)) for k in (0, 5, 6, 7, 8, 9)]
+    variants += [(f"runs32 pad{k}K", (2, 5, k)) for k in (7,)]
+    variants += [(f"runs128 pad{k}K", (2, 7, k)) for k in (7,)]
+    variants += [(f"identity pad{k}K", (0, 0, k)) for k in (6, 7, 8)]
+    variants += [(f"eighths pad{k}K", (1, 0, k)) for k in (4, 7)]
+    variants += [("default again", default)]
     bufs = [("engine", ref)]
     for i in range(args.allocs):
         bufs.append((f"fresh{i}", torch.zeros((B, stride // esz), dtype=ref.dtype, device=vec.device)))
-    print("%-16s" % "variant" + "".join("%18s" % n for n, _ in bufs))
-    for name, xp in variants:
+    print("%-28s" % "configuration" + "".join("%18s" % n for n, _ in bufs))
+    for name, cfg in variants:
         row = []
         for bname, buf in bufs:
-            med, mn = timed(buf, xp, args.reps)
+            med, mn = timed(buf, cfg, args.reps)
             if buf is not ref:
                 assert torch.equal(buf, ref), (name, bname)
             row.append("%9.4f/%8.4f" % (med, mn))
-        # parity of the variant on the engine's buffer against the default's bytes in a fresh buffer
-        print("%-16s" % name + "".join(row), flush=True)
-    eng.set_option("experiment", 0)
+        print("%-28s" % name + "".join(row), flush=True)
+    # the tuner's pick per buffer, and what it measures afterwards
+    row = []
+    for bname, buf in bufs:
+        idx = _capi.check(_capi.lib.pw_engine_tune_render(eng.handle, _capi._ptr(vec.puzzle_id), _capi._ptr(vec.pos),
+                                                          _capi._ptr(buf), stride, B, eng._stream()))
+        cfg = tuple(eng.get_option(k) for k in ("page_order", "page_run_log2", "page_lds_pad_kb"))
+        assert torch.equal(buf, ref), ("tuner", bname)
+        med, mn = timed(buf, cfg, args.reps)
+        row.append("%9.4f %8s" % (med, "#%d%s" % (idx, str(cfg).replace(" ", ""))))
+    print("%-28s" % "tuner pick" + "".join(row))
     # fill_ of the same buffers (pure write ceiling of each allocation)
     row = []
     for bname, buf in bufs:
@@ -106,7 +106,7 @@ def main():
         torch.cuda.synchronize()
         t = np.array([a.elapsed_time(b) for a, b in evs])[2:]
         row.append("%9.4f/%8.4f" % (np.median(t), t.min()))
-    print("%-16s" % "torch zero_" + "".join(row))
+    print("%-28s" % "torch zero_" + "".join(row))
 
 
 if __name__ == "__main__":
