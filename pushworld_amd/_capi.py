@@ -138,6 +138,7 @@ OPTIONS = {
     "page_order": 7,
     "page_run_log2": 8,
     "page_lds_pad_kb": 9,
+    "step_lds_tables": 10,
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1}
 

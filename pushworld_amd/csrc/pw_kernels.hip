@@ -24,6 +24,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "pw_host.h"
@@ -46,6 +47,10 @@ struct PwEngine {
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
   bool page_f32;           // float32, pixels_per_cell 3, border_width 1: page-ordered / delta kernels over a second,
                            // frame-layout zone table (the generic LDS kernel keeps its own layout)
+  bool rowpage;            // any other frame whose pixel rows are whole 16-byte chunks (>= 512 B): the row-page kernel
+  uint8_t* d_srow;         //   over per-puzzle static row tables (3 H distinct pixel rows each)
+  int64_t srow_stride;
+  int row_bytes;
   uint16_t* d_estat_page;
   uint32_t* d_estat_page_off;
   // test / profiling knobs, pw_engine_set_option (all 0 by default)
@@ -54,9 +59,11 @@ struct PwEngine {
   bool force_lds_render;   // PW_OPT_RENDER_KERNEL = 1: per-environment LDS kernel even where the page kernel applies
   int64_t page_slice_envs; // PW_OPT_PAGE_SLICE_ENVS: environments per page-kernel launch (0 = what 2^31 chunks allow)
   int64_t search_chunk;    // PW_OPT_SEARCH_CHUNK: parents per pw_search_expand pass (0 = 2^20)
+  bool step_lds_tables;    // PW_OPT_STEP_LDS_TABLES: the group step kernel stages the puzzle's row tables in LDS (A/B)
   // launch configuration of the page-ordered render kernel (CopyArgs::order / run_log2, dynamic LDS as an
   // occupancy cap); defaults are the robust optimum, pw_engine_tune_render measures the caller's buffer
   int page_order, page_run_log2, page_lds_pad_kb;
+  bool tuning;             // inside pw_engine_tune_render: trial launches use the kTag = 1 symbol of the page kernel
   void* d_rec;             // page records (PageRec [rec_cap]), grown on demand
   int64_t rec_cap;
   // PW_OPT_PROFILE_RENDER: HIP event pairs around the dominant (render) launch, on the launch stream

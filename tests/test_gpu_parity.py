@@ -242,6 +242,57 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     assert torch.equal(ref.render(), alt.render())
 
 
+@pytest.mark.parametrize("obs_kind,ppc,bw,pad,B,cfg", [
+    ("float32", 20, 2, None, 40, None),          # the reference's default observation (10.3 MB each, 10 080-byte rows)
+    ("float32", 20, 2, (54, 47), 24, (1, 0, 4)),  # standard padding (env_utils.py:25-41), eighths
+    ("float32", 8, 2, None, 300, (0, 0, 0)),
+    ("float32", 4, 1, (54, 47), 700, (2, 3, 7)),  # 2 256-byte rows: a page spans three pixel rows
+    ("uint8", 8, 2, None, 700, None),             # 1 008-byte rows: five rows per page
+    ("uint8", 16, 3, None, 200, (2, 6, 0)),
+    ("uint8", 12, 5, (64, 64), 150, None),        # 2 304-byte rows, widest borders, the engine's largest frame
+])
+def test_rowpage_render_matches_lds_kernel(golden, torch_mod, obs_kind, ppc, bw, pad, B, cfg):
+    """The row-page kernel (page-ordered render for frames whose pixel rows are whole 16-byte chunks: copies from
+    per-puzzle static row tables, LDS window under the movables) against the per-environment LDS kernel: byte
+    identical on a mixed Level-1 batch along random walks with autoreset, on overlapping (illegal) states, for both
+    producers of the page records and several page orders."""
+    torch = torch_mod
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    T = 16
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+
+    def make(opts, **kw):
+        return VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=9, pixels_per_cell=ppc,
+                            border_width=bw, observation=obs_kind, pad_cells=pad, device=0, autoreset=True,
+                            engine_options=opts, tune=False, **kw)
+
+    ref = make({"render_kernel": "lds"})
+    alt = make({} if cfg is None else dict(zip(("page_order", "page_run_log2", "page_lds_pad_kb"), cfg)), fused=cfg is None)
+    assert ref.engine.render_kernel == "pw_render_generic_kernel" and alt.engine.render_kernel == "pw_render_rowpage_kernel"
+    o_ref, o_alt = ref.reset(), alt.reset()
+    assert torch.equal(o_ref, o_alt)
+    gen = torch.Generator(device=ref.device)
+    gen.manual_seed(7)
+    acts = torch.randint(0, 4, (T, B), generator=gen, device=ref.device, dtype=torch.uint8)
+    for t in range(T):
+        o_ref = ref.step(acts[t])[0]
+        o_alt = alt.step(acts[t])[0]
+        assert torch.equal(ref.pos, alt.pos)
+        assert torch.equal(o_ref, o_alt), t
+    pos = ref.states()
+    pos[:, 1:] = pos[:, :-1]   # overlapping states: every object at the position of its left neighbour
+    for v in (ref, alt):
+        v.set_states(pos)
+    assert torch.equal(ref.render(), alt.render())
+    if B <= 64:  # the tuner on a small batch of big frames
+        idx = alt.engine.tune_render(alt.puzzle_id, alt.pos, alt._obs_storage)
+        assert 0 <= idx < 14 and torch.equal(alt._obs_storage, ref._obs_storage)
+
+
 def test_page_render_in_slices(golden, torch_mod, monkeypatch):
     """Buffers beyond 2^31 chunks (32 GiB) are rendered in consecutive slices of whole environments; forced
     here with 333-environment slices on a 2 048-environment batch (slice bases are not page aligned)."""

@@ -28,8 +28,10 @@ def main():
     paths = bench.level1_paths()
     B = args.envs
     ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    # fused=True: the bench's path (pw_step_render: the step kernel leaves the page records, no pre-pass); the tuner's
+    # trial launches at reset() run under their own kernel symbol (pw_render_page_kernel<T, 1>)
     vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, border_width=args.bw,
-                       pixels_per_cell=args.ppc, observation=args.obs, device=0, autoreset=True)
+                       pixels_per_cell=args.ppc, observation=args.obs, device=0, autoreset=True, fused=True)
     vec.reset()
     gen = torch.Generator(device=vec.device)
     gen.manual_seed(1)
@@ -38,7 +40,9 @@ def main():
     for t in range(args.steps):
         vec.step(acts[t])
     torch.cuda.synchronize()
-    print("done", args.steps, "steps of", B, "envs; obs bytes/env", vec.engine.obs_bytes)
+    eng = vec.engine
+    print("done", args.steps, "steps of", B, "envs; obs bytes/env", eng.obs_bytes, "render launch config",
+          [eng.get_option(k) for k in ("page_order", "page_run_log2", "page_lds_pad_kb")], "tuned", vec.tuned_config)
 
 
 if __name__ == "__main__":
