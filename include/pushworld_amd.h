@@ -158,8 +158,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_PAGE_RUN_LOG2 8     /* log2 of the run length of order 2 (default 6) */
 #define PW_OPT_PAGE_LDS_PAD_KB 9   /* KiB of unused dynamic LDS per workgroup: caps the workgroups per CU, i.e. the width
                                       of the chip-wide write front (default 7 for uint8, 8 for float32 observations) */
-#define PW_OPT_STEP_LDS_TABLES 10   /* 1: the lane-group step kernel copies the puzzle's wall / shape row bitboards into LDS
-                                      first and reads them from there (A/B variant; measured slower) */
+#define PW_OPT_STEP_LDS_TABLES 10   /* the lane-group step kernel copies the puzzle's wall / shape row bitboards into LDS first
+                                      and reads them from there: 0 automatic (launches of >= 4 steps, where it measured
+                                      5-18 % faster; one step per launch: no difference), 1 always, 2 never */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

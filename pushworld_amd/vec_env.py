@@ -34,8 +34,8 @@ class VecPushWorld:
         pad_cells: (height, width) of the observation frame in cells; default = pool maximum
             (gym_env.py:80-82).
         autoreset: next-step autoreset inside the step kernel.
-        fused: one ``pw_step_render`` call per step (the library picks the schedule: step kernel +
-            page-ordered render, or a single fused launch) instead of ``pw_step`` + ``pw_render``.
+        fused: one ``pw_step_render`` call per step (default: the step kernel hands its page records to the
+            page-ordered render, no pre-pass) instead of ``pw_step`` + ``pw_render``.
         incremental: keep the observation buffer up to date with ``pw_step_render_delta``: a step
             rewrites only the pixel rows swept by the objects that moved (the buffer persists between
             steps, so everything else is already right).  Same observations, a fraction of the HBM
@@ -57,7 +57,7 @@ class VecPushWorld:
                  puzzle_ids: Optional[Sequence[int]] = None, max_steps: Optional[int] = None,
                  border_width: int = DEFAULT_BORDER_WIDTH, pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL,
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
-                 autoreset: bool = False, fused: bool = False, resample=False, seed: int = 0,
+                 autoreset: bool = False, fused: bool = True, resample=False, seed: int = 0,
                  incremental: bool = False, engine_options: Optional[dict] = None, tune: Optional[bool] = None):
         if observation not in ("uint8", "float32", None):
             raise ValueError("observation must be 'uint8', 'float32' or None")

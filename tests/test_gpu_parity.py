@@ -40,7 +40,16 @@ def _groups(golden):
     return g
 
 
+def _step_options(kernel):
+    """engine options of a step-kernel flavour: "group" (default: row tables read from global memory for single
+    steps), "group-lds" (row tables staged in LDS, the default of multi-step rollouts), "lane", "wave"."""
+    if kernel == "group-lds":
+        return {"step_kernel": "group", "step_lds_tables": 1}
+    return {"step_kernel": kernel, "step_lds_tables": 2}
+
+
 @pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
+                                          ("bench", "group-lds"), ("tests", "group-lds"), ("l0", "group-lds"),
                                           ("bench", "lane"), ("tests", "lane"), ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
@@ -60,7 +69,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
     T = max(len(e[2][1]) for e in envs)
     max_steps = 50
     vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=max_steps, observation=None, device=0,
-                       engine_options={"step_kernel": kernel})
+                       engine_options=_step_options(kernel))
     vec.reset()
     NP = vec.num_objects_padded
     # start states
@@ -99,7 +108,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["group", "lane", "wave"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "lane", "wave"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
@@ -115,7 +124,7 @@ def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypat
             ids.append(pi)
             rows.append((k, s))
     B = len(ids)
-    vec = VecPushWorld(pool, B, puzzle_ids=ids, observation=None, device=0, engine_options={"step_kernel": kernel})
+    vec = VecPushWorld(pool, B, puzzle_ids=ids, observation=None, device=0, engine_options=_step_options(kernel))
     vec.reset()
     NP = vec.num_objects_padded
     base = np.zeros((B, NP, 2), np.int8)
@@ -364,7 +373,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
                 assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
 
 
-@pytest.mark.parametrize("kernel", ["group", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "lane"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):
     """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's
@@ -388,7 +397,7 @@ def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, ke
         actions[n:, b] = (np.arange(T - n) + b) % 4
     acts = torch.as_tensor(actions).to("cuda:0")
     ids = [e[0] for e in envs]
-    opts = {"step_kernel": kernel}
+    opts = _step_options(kernel)
     a = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset,
                      engine_options=opts)
     b_ = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset,

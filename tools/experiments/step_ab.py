@@ -63,7 +63,7 @@ def main():
     print("library:", os.path.basename(_capi.LIB_PATH))
     print("%-28s %-10s %14s %14s %16s %16s" % ("workload", "tables", "step us med", "step us min", "rollout64 us", "rollout steps/s"))
     for name, pool, B, ids in workloads():
-        for lds in (0, 1):
+        for lds in (2, 1):  # 2 = never (global rows through L1), 1 = always LDS
             vec = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=200, observation=None, autoreset=True)
             try:
                 vec.engine.set_option("step_lds_tables", lds)
@@ -81,7 +81,7 @@ def main():
 
             med, mn = timed(one, args.reps)
             rmed, _ = timed(lambda: vec.rollout(acts), max(10, args.reps // 4))
-            print("%-28s %-10s %14.2f %14.2f %16.1f %16.3e" % (name, "lds" if lds else "global", med, mn, rmed, 64 * B / (rmed * 1e-6)),
+            print("%-28s %-10s %14.2f %14.2f %16.1f %16.3e" % (name, "lds" if lds == 1 else "global", med, mn, rmed, 64 * B / (rmed * 1e-6)),
                   flush=True)
             del vec
 
