@@ -93,18 +93,26 @@ def cpu_baseline(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw, targ
         hw = len(os.sched_getaffinity(0))
     except AttributeError:
         hw = os.cpu_count() or 1
+    def calibrated_rate(threads):
+        """rate from a run long enough (>= 0.3 s) that thread start-up does not dominate"""
+        timed(2, threads)  # warm (thread pool, caches)
+        T = 16
+        while True:
+            rate, used, dt = timed(T, threads)
+            if dt >= 0.3 or T >= 8192:
+                return rate, used
+            T *= 4
+
     best = None
     for cand in sorted({hw, max(1, hw // 2)}):
-        timed(2, cand)  # warm (thread pool, caches)
-        rate = timed(8, cand)[0]
+        rate = calibrated_rate(cand)[0]
         if best is None or rate > best[1]:
             best = (cand, rate)
     all_threads = best[0]
     out = {}
     for label, threads, budget in (("all", all_threads, target_seconds), ("one", 1, target_seconds * 0.4)):
-        timed(2, threads)
-        rate, used_threads, _ = timed(8, threads)
-        T2 = int(max(4, min(16384, budget * rate / B)))
+        rate, used_threads = calibrated_rate(threads)
+        T2 = int(max(4, min(65536, budget * rate / B)))
         rate, used_threads, dt = timed(T2, threads)
         out[label] = (rate, used_threads, T2, dt)
     what = f"step + padded uint8 render ppc={ppc}" if render else "step only (no observation)"

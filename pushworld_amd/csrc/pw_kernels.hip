@@ -47,9 +47,11 @@ struct PwEngine {
   bool fast_u8_ppc3;       // uint8, pixels_per_cell 3, border_width 1: zones == pixels
   bool page_f32;           // float32, pixels_per_cell 3, border_width 1: page-ordered / delta kernels over a second,
                            // frame-layout zone table (the generic LDS kernel keeps its own layout)
-  bool rowpage;            // any other frame whose pixel rows are whole 16-byte chunks (>= 512 B): the row-page kernel
-  uint8_t* d_srow;         //   over per-puzzle static row tables (3 H distinct pixel rows each)
+  bool rowpage;            // any other frame with pixel rows of >= 512 bytes: the row-page kernel over per-puzzle
+  bool rowpage_aligned;    //   static row tables (3 H distinct pixel rows + a zero row); aligned: rows are whole chunks
+  uint8_t* d_srow;
   int64_t srow_stride;
+  int srow_pitch;
   int row_bytes;
   uint16_t* d_estat_page;
   uint32_t* d_estat_page_off;

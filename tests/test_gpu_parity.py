@@ -259,6 +259,13 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     ("uint8", 8, 2, None, 700, None),             # 1 008-byte rows: five rows per page
     ("uint8", 16, 3, None, 200, (2, 6, 0)),
     ("uint8", 12, 5, (64, 64), 150, None),        # 2 304-byte rows, widest borders, the engine's largest frame
+    # pixel rows that are NOT whole 16-byte chunks: unaligned source loads + one straddling chunk per row
+    ("uint8", 20, 2, None, 100, None),            # 2 520-byte rows (the reference's rgb_array size, 2.6 MB each)
+    ("uint8", 20, 2, (54, 47), 60, (1, 0, 7)),    # 2 820-byte rows
+    ("uint8", 5, 1, None, 1500, (2, 2, 7)),       # 630-byte rows: seven rows per page
+    ("uint8", 7, 3, (51, 43), 600, (0, 0, 0)),    # 903-byte rows (odd), border = whole cell but one pixel
+    ("float32", 5, 2, (52, 43), 300, None),       # 2 580-byte rows (a multiple of 4, not of 16)
+    ("float32", 3, 1, (54, 47), 60, None),        # ppc 3 float32 keeps its own page kernel (control case)
 ])
 def test_rowpage_render_matches_lds_kernel(golden, torch_mod, obs_kind, ppc, bw, pad, B, cfg):
     """The row-page kernel (page-ordered render for frames whose pixel rows are whole 16-byte chunks: copies from
@@ -281,7 +288,10 @@ def test_rowpage_render_matches_lds_kernel(golden, torch_mod, obs_kind, ppc, bw,
 
     ref = make({"render_kernel": "lds"})
     alt = make({} if cfg is None else dict(zip(("page_order", "page_run_log2", "page_lds_pad_kb"), cfg)), fused=cfg is None)
-    assert ref.engine.render_kernel == "pw_render_generic_kernel" and alt.engine.render_kernel == "pw_render_rowpage_kernel"
+    if ppc == 3:
+        assert alt.engine.render_kernel == "pw_render_page_kernel"
+    else:
+        assert ref.engine.render_kernel == "pw_render_generic_kernel" and alt.engine.render_kernel == "pw_render_rowpage_kernel"
     o_ref, o_alt = ref.reset(), alt.reset()
     assert torch.equal(o_ref, o_alt)
     gen = torch.Generator(device=ref.device)
