@@ -229,7 +229,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each (median reported)")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="timed windows of --steps steps each (median reported); 0 = as many as fill --min-seconds, at least 7")
+    ap.add_argument("--min-seconds", type=float, default=5.0,
+                    help="with --windows 0: total timed GPU work (long enough for a device-utilisation sampler to see it)")
     ap.add_argument("--config", choices=["c3", "c4"], default="c3")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--ppc", type=int, default=3)
@@ -248,8 +251,8 @@ def main():
     args = ap.parse_args()
     if args.obs is None:
         args.obs = "uint8" if args.config == "c3" else "none"
-    if args.gpus < 1 or args.steps < 1 or args.windows < 1:
-        raise SystemExit("--gpus, --steps and --windows must be >= 1")
+    if args.gpus < 1 or args.steps < 1 or args.windows < 0:
+        raise SystemExit("--gpus and --steps must be >= 1, --windows >= 0")
 
     in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if not in_torchrun and args.gpus > 1:
@@ -293,13 +296,13 @@ def main():
     eng = vec.engine
     dev = vec.device
     B = args.envs_per_gpu
-    K, Wm, M = args.steps, args.warmup, args.windows
+    K, Wm = args.steps, args.warmup
     obs_mode = None if args.obs == "none" else args.obs
     if args.fused:
         eng.set_option("fused_step_render", 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed((C4_SEED if args.config == "c4" else 1) + rank)
-    n_act = min(Wm + K * M, 4096)  # the action stream is reused cyclically beyond 4 096 steps
+    n_act = min(Wm + K * max(args.windows, 200), 2048)  # the action stream is reused cyclically beyond that
     actions = torch.randint(0, 4, (n_act, B), generator=gen, device=dev, dtype=torch.uint8)
 
     vec.reset()
@@ -324,14 +327,27 @@ def main():
             eng.step_render(vec.puzzle_id, a, vec.pos, vec.steps, vec.reward, vec.dgoals, vec.terminated,
                             vec.truncated, vec._obs_storage, vec.flags)
 
-    for t in range(Wm):
-        one_step(t)
-    if obs_mode is not None:
-        eng.profile_render(K * M)
-
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    from pushworld_amd.sharding import gather_floats, reduce_counters, reduce_max
+
+    for t in range(Wm):
+        one_step(t)
+    M = args.windows
+    if M == 0:
+        # one untimed calibration window (MAX over ranks, so every rank derives the same window count)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(K):
+            one_step(Wm + t)
+        torch.cuda.synchronize()
+        t_window = reduce_max([time.perf_counter() - t0], device=red_dev)[0]
+        M = int(min(max(7, np.ceil(args.min_seconds / max(t_window, 1e-6))), max(7, 60000 // K)))
+    if obs_mode is not None:
+        eng.profile_render(K * M)
 
     windows = []
     t_next = Wm
@@ -350,8 +366,6 @@ def main():
 
     # the collectives of the whole job: SUM of the step counters, MAX of every window (a few bytes), and the
     # per-rank medians gathered for the report
-    from pushworld_amd.sharding import gather_floats, reduce_counters, reduce_max
-
     own_median = float(np.median(windows))
     counters, _ = reduce_counters({"env_steps": B * K, "ranks": 1}, own_median, device=red_dev)
     win_max = reduce_max(windows, device=red_dev)  # per window: the slowest rank
@@ -408,7 +422,7 @@ def main():
             "windows": M,
             "steps_per_window": K,
             "statistic": "median over windows of (max over ranks)",
-            "window_ms_per_step": [1000.0 * w / K for w in win_max],
+            "window_ms_per_step": [1000.0 * w / K for w in (win_max if M <= 16 else win_max[:8] + win_max[-8:])],
             "min_ms_per_step": 1000.0 * min(win_max) / K,
             "max_ms_per_step": 1000.0 * max(win_max) / K,
             "per_rank_median_ms_per_step": [1000.0 * w / K for w in per_rank],
