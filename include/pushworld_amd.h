@@ -134,6 +134,47 @@ int pw_puzzleset_blob(const PwPuzzleSet* s, const void** data, size_t* bytes);
 int pw_puzzleset_save(const PwPuzzleSet* s, const char* path);
 int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out);
 
+/* ------------------------------------------------ generation / transforms / packing on the device
+ * A puzzle as a *symbol grid*: one byte per cell of the file's grid (without the border walls the parser adds),
+ * row-major in a square slot of slot_w x slot_w bytes, one element per cell.  The generator, the transform and the
+ * packer are kernels: generate -> (transform) -> pack -> train never goes through puzzle text.  The packer writes
+ * exactly the tables pw_puzzle_parse + pw_puzzleset_create produce for the same puzzle. */
+#define PW_SYM_EMPTY 0x00   /* "."                                                    */
+#define PW_SYM_WALL 0x01    /* "W"                                                    */
+#define PW_SYM_AWALL 0x02   /* "AW"                                                   */
+#define PW_SYM_AGENT 0x03   /* "A"                                                    */
+#define PW_SYM_MOVABLE 0x40 /* "M<k>" = PW_SYM_MOVABLE | k, k < 48                     */
+#define PW_SYM_GOAL 0x80    /* "G<k>" = PW_SYM_GOAL | k                                */
+
+typedef struct PwGenConfig {   /* generate_level0_puzzles, generate.py:136-259 (same meaning, inclusive ranges) */
+  uint64_t seed;               /* puzzle i of a seed is a pure function of (seed, i): counter-based pw_mix64 stream */
+  int32_t min_size, max_size;  /* width and height of the file grid, drawn independently; max_size = slot width   */
+  int32_t min_walls, max_walls;
+  int32_t min_obstacles, max_obstacles;
+  int32_t min_goal_objects, max_goal_objects; /* 1 .. 2 */
+  int32_t complex_shapes;      /* 0: single cells ("simple"), 1: + dominoes and trominoes ("complex")            */
+} PwGenConfig;
+
+/* Puzzles first .. first + count - 1 of the stream: grids uint8 [count][max_size * max_size], dims int32 [count][2]
+ * (width, height; 0 0 if no puzzle could be completed).  device >= 0: device buffers, one thread per puzzle;
+ * device < 0: the same function on the host (host buffers) -- identical output. */
+int pw_generate_level0(int device, const PwGenConfig* cfg, uint64_t first, int32_t count, uint8_t* grids,
+                       int32_t* dims, void* stream);
+/* The 8 dihedral variants of every grid (transform.py:21-48): out uint8 [count][8][slot_w * slot_w], out_dims int32
+ * [count][8][2]; variant v = 4 * flipped + clockwise quarter turns (names r0 r90 r180 r270 r0_flipped ...), the
+ * top-bottom flip applied before the rotation. */
+int pw_transform_grids(int device, const uint8_t* grids, const int32_t* dims, int32_t count, int32_t slot_w,
+                       uint8_t* out, int32_t* out_dims, void* stream);
+/* Packs `count` device-resident grids into a puzzle set on `device` (one wavefront per puzzle) -- the device-side
+ * pw_puzzle_parse + pw_puzzleset_create.  Errors as the parser's: PW_EPARSE (no agent), PW_EGOAL (goal without
+ * movable), PW_ELIMIT.  Synchronises `stream`. */
+int pw_puzzleset_from_grids(int device, const uint8_t* grids, const int32_t* dims, int32_t count, int32_t slot_w,
+                            int order, PwPuzzleSet** out, void* stream);
+/* .pwp text of a HOST grid (two spaces between tokens like generate.py:133); returns the length, writes <= cap - 1 chars */
+int pw_grid_to_text(const uint8_t* grid, int32_t width, int32_t height, int32_t slot_w, char* buf, int32_t cap);
+/* packed header array (host copy), for tests */
+int pw_puzzleset_headers(const PwPuzzleSet* s, const void** data, size_t* bytes);
+
 /* ---------------------------------------------------------------------- engine */
 int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine** out);
 void pw_engine_destroy(PwEngine* e);

@@ -39,6 +39,17 @@ class PwPuzzleInfo(ctypes.Structure):
     ]
 
 
+class PwGenConfig(ctypes.Structure):
+    _fields_ = [
+        ("seed", ctypes.c_uint64),
+        ("min_size", c_int32), ("max_size", c_int32),
+        ("min_walls", c_int32), ("max_walls", c_int32),
+        ("min_obstacles", c_int32), ("max_obstacles", c_int32),
+        ("min_goal_objects", c_int32), ("max_goal_objects", c_int32),
+        ("complex_shapes", c_int32),
+    ]
+
+
 class PwEngineConfig(ctypes.Structure):
     _fields_ = [
         ("max_steps", c_int32),
@@ -119,6 +130,11 @@ SIGNATURES = {
          c_int64, c_int32, c_uint32, c_void_p],
     ),
     "pw_expand4": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "pw_generate_level0": (c_int, [c_int, POINTER(PwGenConfig), ctypes.c_uint64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "pw_transform_grids": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "pw_puzzleset_from_grids": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int, POINTER(c_void_p), c_void_p]),
+    "pw_grid_to_text": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_char_p, c_int32]),
+    "pw_puzzleset_headers": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
     "pw_engine_set_option": (c_int, [c_void_p, c_int32, c_int64]),
     "pw_engine_get_option": (c_int64, [c_void_p, c_int32]),
     "pw_engine_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_float), c_int32]),
@@ -300,9 +316,34 @@ class PuzzleSet:
         self._read_dims()
         return self
 
+    @classmethod
+    def from_grids(cls, grids, dims, device: int, order: int = ORDER_PYTHON) -> "PuzzleSet":
+        """A set packed ON THE DEVICE from symbol grids (``pw_puzzleset_from_grids``): ``grids`` uint8 tensor
+        [count, slot_w * slot_w], ``dims`` int32 tensor [count, 2] on ``device``; ``puzzles`` is None."""
+        self = cls.__new__(cls)
+        self.puzzles = None
+        slot_w = int(round(grids.shape[-1] ** 0.5))
+        if slot_w * slot_w != grids.shape[-1] or dims.shape != (grids.shape[0], 2):
+            raise ValueError("grids must be [count, slot_w * slot_w] with dims [count, 2]")
+        h = c_void_p()
+        stream = c_void_p(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
+        check(lib.pw_puzzleset_from_grids(device, _ptr(grids), _ptr(dims), grids.shape[0], slot_w, order, ctypes.byref(h),
+                                          stream))
+        self.handle = h
+        self.device = device
+        self.count = lib.pw_puzzleset_size(h)
+        self._read_dims()
+        return self
+
     def blob(self) -> bytes:
         p, n = c_void_p(), c_size_t()
         check(lib.pw_puzzleset_blob(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p.value, n.value)
+
+    def headers(self) -> bytes:
+        """The packed ``PwPuzzleHeader`` array (320 bytes per puzzle, csrc/pw_format.h)."""
+        p, n = c_void_p(), c_size_t()
+        check(lib.pw_puzzleset_headers(self.handle, ctypes.byref(p), ctypes.byref(n)))
         return ctypes.string_at(p.value, n.value)
 
     def __del__(self):

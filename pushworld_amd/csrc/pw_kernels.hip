@@ -248,3 +248,4 @@ struct PageRec {
 #include "pw_render_kernels.inc"
 #include "pw_engine.inc"
 #include "pw_search.inc"
+#include "pw_generate.inc"

@@ -52,8 +52,8 @@ class BreadthFirstSearch:
         self.novelty_width = int(novelty_width)
         self._engine.set_option("search_chunk", 0 if chunk is None else int(chunk))
         try:
-            _capi.check(_capi.lib.pw_search_create(self._engine.handle, 0, self.max_states, self.novelty_width,
-                                                   ctypes.byref(h)))
+            _capi.check(_capi.lib.pw_search_create(self._engine.handle, int(getattr(puzzle, "puzzle_index", 0)),
+                                                   self.max_states, self.novelty_width, ctypes.byref(h)))
         finally:
             self._engine.set_option("search_chunk", 0)
         self.handle = h
@@ -149,6 +149,27 @@ class BreadthFirstSearch:
             self.handle = None
 
     __del__ = close
+
+
+class SetPuzzle:
+    """Puzzle ``index`` of a packed ``_capi.PuzzleSet`` as ``BreadthFirstSearch`` needs it (number of movables,
+    initial state, goal test, a state-only engine shared by all puzzles of the set) -- for sets that never existed
+    as text (``generate.generate_level0_set``).  Reads the packed header (csrc/pw_format.h)."""
+
+    def __init__(self, pset: "_capi.PuzzleSet", index: int, engine: Optional["_capi.Engine"] = None):
+        hdr = pset.headers()[320 * index:320 * (index + 1)]
+        self.puzzle_index = int(index)
+        self.num_movables, n_goals = hdr[6], hdr[7]
+        i8 = np.frombuffer(hdr, dtype=np.int8)
+        self.initial_state = tuple((int(i8[256 + 2 * j]), int(i8[257 + 2 * j])) for j in range(self.num_movables))
+        self.goal_state = tuple((int(i8[192 + 2 * g]), int(i8[193 + 2 * g])) for g in range(n_goals))
+        self._eng = engine if engine is not None else _capi.Engine(pset, None, 3, 1, _capi.OBS_U8)
+
+    def _engine(self):
+        return self._eng
+
+    def is_goal_state(self, state) -> bool:
+        return tuple(tuple(int(v) for v in p) for p in state[1:1 + len(self.goal_state)]) == self.goal_state
 
 
 class NoveltyTables:

@@ -35,6 +35,28 @@ def get_puzzle_transforms(puzzle_string: str) -> Dict[str, str]:
     return out
 
 
+def transform_grids(grids, dims):
+    """The 8 variants of every symbol grid ON THE DEVICE (``pw_transform_grids``): ``grids`` uint8 [n, S * S] and
+    ``dims`` int32 [n, 2] device tensors -> ``(uint8 [8 n, S * S], int32 [8 n, 2])``, variant ``v`` of puzzle ``i``
+    at row ``8 i + v`` in the order of ``TRANSFORM_NAMES``."""
+    import ctypes
+
+    import torch
+
+    from . import _capi
+
+    n, cells = grids.shape
+    slot_w = int(round(cells ** 0.5))
+    if slot_w * slot_w != cells or dims.shape != (n, 2) or grids.dtype != torch.uint8 or dims.dtype != torch.int32:
+        raise ValueError("grids must be uint8 [n, S * S] and dims int32 [n, 2]")
+    out = torch.empty((n * 8, cells), dtype=torch.uint8, device=grids.device)
+    out_dims = torch.empty((n * 8, 2), dtype=torch.int32, device=grids.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(grids.device).cuda_stream)
+    _capi.check(_capi.lib.pw_transform_grids(grids.device.index, _capi._ptr(grids), _capi._ptr(dims), n, slot_w,
+                                             _capi._ptr(out), _capi._ptr(out_dims), stream))
+    return out, out_dims
+
+
 def transform_plan(plan: Sequence[int], transform_name: str) -> List[int]:
     """The plan that does in the transformed puzzle what ``plan`` does in the original
     (the mapping python3/test/test_transform.py:47-79 checks)."""
