@@ -175,7 +175,7 @@ def build_workload(args, rank, world, device_index):
         ids = (np.arange(B, dtype=np.int64) * len(paths)) // B  # grouped by puzzle, ~964 envs each
         vec = VecPushWorld([PushWorldPuzzle(text=t) for t in texts], B, puzzle_ids=ids, max_steps=args.max_steps,
                            border_width=args.bw, pixels_per_cell=args.ppc, observation=obs_mode, device=device_index,
-                           autoreset=True)
+                           autoreset=True, tune_allocations=args.tune_allocations)
         label = "C3: Level-1 mix (68 puzzles, envs grouped by puzzle), step + RGB render every step" if obs_mode else \
             "C3 puzzles (Level-1 mix), state only"
         return dict(vec=vec, texts=texts, ids=ids, label=label, n_puzzles=len(texts))
@@ -195,7 +195,7 @@ def build_workload(args, rank, world, device_index):
     pset = _capi.PuzzleSet([_capi.ParsedPuzzle(t) for t in texts], device_index)
     vec = VecPushWorld(pset, B, puzzle_ids=ids, max_steps=args.max_steps, border_width=args.bw,
                        pixels_per_cell=args.ppc, observation=obs_mode, pad_cells=(54, 47), device=device_index,
-                       autoreset=True)
+                       autoreset=True, tune_allocations=args.tune_allocations)
     label = (f"C4 shard: {n_l0} Level-0 train puzzles (50 % of envs) + {n_hi} Level-1..4 puzzles (50 %), frame 54x47, "
              + ("step + uint8 ppc-3 render" if obs_mode else "state only"))
     return dict(vec=vec, texts=texts, ids=ids, label=label, n_puzzles=len(texts))
@@ -248,6 +248,8 @@ def main():
                     help="plumbing test on a 1-GPU box: all ranks on cuda:0, gloo for the counter reduction "
                          "(RCCL refuses two ranks on one device)")
     ap.add_argument("--fused", type=int, default=0, help="1: single fused step+render launch (engine option)")
+    ap.add_argument("--tune-allocations", type=int, default=4,
+                    help="candidate allocations of the observation buffer the tuner chooses among (VecPushWorld)")
     args = ap.parse_args()
     if args.obs is None:
         args.obs = "uint8" if args.config == "c3" else "none"
@@ -414,7 +416,8 @@ def main():
                            + (f" (counters over {backend})" if backend else ""),
             # launch configuration of the page-ordered render kernel on rank 0 (pw_engine_tune_render at the first
             # reset: same bytes, the fastest of 14 page orders / occupancies for THIS observation buffer)
-            "render_launch": {"tuned_index": vec.tuned_config, "page_order": eng.get_option("page_order"),
+            "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
+                              "allocations_tried": args.tune_allocations, "page_order": eng.get_option("page_order"),
                               "page_run_log2": eng.get_option("page_run_log2"),
                               "page_lds_pad_kb": eng.get_option("page_lds_pad_kb")},
         },

@@ -202,6 +202,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_STEP_LDS_TABLES 10   /* the lane-group step kernel copies the puzzle's wall / shape row bitboards into LDS first
                                       and reads them from there: 0 automatic (launches of >= 4 steps, where it measured
                                       5-18 % faster; one step per launch: no difference), 1 always, 2 never */
+#define PW_OPT_TUNED_NS 11          /* read-only: nanoseconds per render launch measured for the configuration the last
+                                      pw_engine_tune_render kept (0 before the first call) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

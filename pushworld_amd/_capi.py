@@ -155,6 +155,7 @@ OPTIONS = {
     "page_run_log2": 8,
     "page_lds_pad_kb": 9,
     "step_lds_tables": 10,
+    "tuned_ns": 11,          # read-only
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1}
 

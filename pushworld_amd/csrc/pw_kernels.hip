@@ -67,6 +67,7 @@ struct PwEngine {
   // launch configuration of the page-ordered render kernel (CopyArgs::order / run_log2, dynamic LDS as an
   // occupancy cap); defaults are the robust optimum, pw_engine_tune_render measures the caller's buffer
   int page_order, page_run_log2, page_lds_pad_kb;
+  int64_t tuned_ns;        // nanoseconds per launch of the configuration pw_engine_tune_render kept (0: never tuned)
   bool tuning;             // inside pw_engine_tune_render: trial launches use the kTag = 1 symbol of the page kernel
   void* d_rec;             // page records (PageRec [rec_cap]), grown on demand
   int64_t rec_cap;
