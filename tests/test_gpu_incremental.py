@@ -121,7 +121,8 @@ def test_incremental_generic_kernel_equals_full_render(golden, kw):
         assert torch.equal(full.step(a)[0], inc.step(a)[0]), t
 
 
-def test_incremental_with_large_pool_static_images_in_hbm(golden):
+@pytest.mark.parametrize("cfg", [None, (0, 0, 0), (1, 0, 7), (2, 4, 3)])
+def test_incremental_with_large_pool_static_images_in_hbm(golden, cfg):
     """860 puzzles of every size in a 64 x 64 frame: 95 MB of static images, of which the page-ordered kernel reads
     only each puzzle's own pixel rows (the frame padding above and below is neither loaded nor computed).  The
     page-ordered full render, the per-environment LDS kernel and the incremental path stay byte-identical, through
@@ -134,7 +135,8 @@ def test_incremental_with_large_pool_static_images_in_hbm(golden):
     ids = np.arange(B) % len(pool)
     kw = dict(puzzle_ids=ids, max_steps=17, pixels_per_cell=3, border_width=1, observation="uint8", pad_cells=(64, 64),
               autoreset=True, resample=True, seed=3)
-    full = VecPushWorld(pool, B, **kw)
+    opts = {} if cfg is None else dict(zip(("page_order", "page_run_log2", "page_lds_pad_kb"), cfg))
+    full = VecPushWorld(pool, B, engine_options=opts, **kw)
     lds = VecPushWorld(pool, B, engine_options={"render_kernel": "lds"}, **kw)
     inc = VecPushWorld(pool, B, incremental=True, **kw)
     assert full.engine.render_kernel == "pw_render_page_kernel" and lds.engine.render_kernel == "pw_render_u8_ppc3_kernel"
