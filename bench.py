@@ -248,7 +248,7 @@ def main():
                     help="plumbing test on a 1-GPU box: all ranks on cuda:0, gloo for the counter reduction "
                          "(RCCL refuses two ranks on one device)")
     ap.add_argument("--fused", type=int, default=0, help="1: single fused step+render launch (engine option)")
-    ap.add_argument("--tune-allocations", type=int, default=4,
+    ap.add_argument("--tune-allocations", type=int, default=6,
                     help="candidate allocations of the observation buffer the tuner chooses among (VecPushWorld)")
     args = ap.parse_args()
     if args.obs is None:
