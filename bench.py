@@ -415,7 +415,7 @@ def main():
             "parallelism": f"env-sharded x{world}, no data-path collective"
                            + (f" (counters over {backend})" if backend else ""),
             # launch configuration of the page-ordered render kernel on rank 0 (pw_engine_tune_render at the first
-            # reset: same bytes, the fastest of 14 page orders / occupancies for THIS observation buffer)
+            # reset: same bytes, the fastest of 16 page orders / occupancies for THIS observation buffer)
             "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
                               "allocations_tried": args.tune_allocations, "page_order": eng.get_option("page_order"),
                               "page_run_log2": eng.get_option("page_run_log2"),

@@ -194,9 +194,10 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_SEARCH_CHUNK 5      /* pw_search_create: parents per expansion pass (0 = 2^20) */
 #define PW_OPT_PROFILE_RENDER 6    /* n > 0: time the next n render launches with HIP events on their stream */
 /* launch configuration of the page-ordered render kernel (same bytes, different speed; see pw_engine_tune_render) */
-#define PW_OPT_PAGE_ORDER 7        /* which 4 KiB page a workgroup writes: 0 page = workgroup index, 1 every XCD sweeps
-                                      one contiguous eighth of the buffer, 2 every XCD writes runs of 2^RUN_LOG2 pages */
-#define PW_OPT_PAGE_RUN_LOG2 8     /* log2 of the run length of order 2 (default 6) */
+#define PW_OPT_PAGE_ORDER 7        /* which 4 KiB page a workgroup writes: 0 page = workgroup index, 1 the buffer in 8 >> RUN_LOG2
+                                      contiguous parts, XCD k sweeping part k mod parts (RUN_LOG2 0: one eighth per XCD,
+                                      1: quarters shared by two XCDs), 2 every XCD writes runs of 2^RUN_LOG2 pages */
+#define PW_OPT_PAGE_RUN_LOG2 8     /* log2 of the run length of order 2 (default 6) / parts selector of order 1 */
 #define PW_OPT_PAGE_LDS_PAD_KB 9   /* KiB of unused dynamic LDS per workgroup: caps the workgroups per CU, i.e. the width
                                       of the chip-wide write front (default 7 for uint8, 8 for float32 observations) */
 #define PW_OPT_STEP_LDS_TABLES 10   /* the lane-group step kernel copies the puzzle's wall / shape row bitboards into LDS first
