@@ -70,8 +70,8 @@ def main():
     variants += [(f"runs128 pad{k}K", (2, 7, k)) for k in (7,)]
     variants += [(f"identity pad{k}K", (0, 0, k)) for k in (6, 7, 8)]
     variants += [(f"eighths pad{k}K", (1, 0, k)) for k in (4, 7)]
-    variants += [(f"quarters pad{k}K", (1, 1, k)) for k in (0, 4, 7)]
-    variants += [(f"halves pad{k}K", (1, 2, k)) for k in (0, 4, 7)]
+    variants += [(f"quarters pad{k}K", (1, 1, k)) for k in (5, 6, 7, 8, 9, 10)]
+    variants += [(f"halves pad{k}K", (1, 2, k)) for k in (4, 7)]
     variants += [("default again", default)]
     bufs = [("engine", ref)]
     for i in range(args.allocs):
