@@ -160,7 +160,12 @@ class VecPushWorld:
         eng = self.engine
         keys = ("page_order", "page_run_log2", "page_lds_pad_kb")
         best = None
-        candidates = [(self._obs_storage, self.obs)] + [eng.alloc_obs(self.num_envs) for _ in range(self._tune_allocations - 1)]
+        candidates = [(self._obs_storage, self.obs)]
+        for _ in range(self._tune_allocations - 1):
+            try:
+                candidates.append(eng.alloc_obs(self.num_envs))
+            except RuntimeError:  # out of memory: tune on the candidates there are
+                break
         for storage, view in candidates:
             idx = eng.tune_render(self.puzzle_id, self.pos, storage)
             ns = eng.get_option("tuned_ns")
