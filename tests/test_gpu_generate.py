@@ -205,6 +205,19 @@ def test_generated_set_trains_like_the_text_pool(torch_mod):
     dev.engine.validate(dev.puzzle_id, dev.pos)
 
 
+def test_device_packed_set_survives_the_pool_file(torch_mod, tmp_path):
+    """A device-generated set through pw_puzzleset_save / pw_puzzleset_load: the loader's extent and
+    index validation accepts the packer's fixed-slot blob, and the loaded set has the same tables."""
+    from pushworld_amd import _capi, generate
+
+    pset, _, _ = generate.generate_level0_set(200, device=0, random_seed=6, max_num_goal_objects=2)
+    path = str(tmp_path / "generated.pwset")
+    pset.save(path)
+    back = _capi.PuzzleSet.load(path, 0)
+    assert len(back) == 200 and back.blob() == pset.blob() and back.headers() == pset.headers()
+    assert (back.max_width, back.max_height, back.max_movables) == (pset.max_width, pset.max_height, pset.max_movables)
+
+
 def test_solvability_filter_on_a_device_generated_set(torch_mod):
     """The filter of generate.py:262-297 on a set that never existed as text (search by set index): verdicts equal
     those of ``generate.solve`` on the texts of the same puzzles."""
