@@ -9,7 +9,7 @@
 
 #include <stdint.h>
 
-#define PW_FMT_MAGIC 0x50573031u /* "PW01" */
+#define PW_FMT_MAGIC 0x50573032u /* "PW02" */
 
 // palette indices written by the render kernel (RGB values: puzzle.py:65-79)
 enum PwColor {
@@ -73,10 +73,21 @@ struct PwPuzzleHeader {
   uint32_t off_mcells;   // uint32[n_mcells]: cx | cy<<8 | absent mask<<16 | object<<24
   uint32_t n_mcells;
   uint32_t has_aw;
-  uint32_t reserved[7];
+  uint32_t off_small;    // uint64[N]  8x8 bitboard of every movable with w, h <= 8 (bit 8 * row + column), 0 otherwise:
+                         //            the push / wall tests of small objects run on it without touching the shape rows
+  uint32_t reserved[6];
   PwObjEntry objtab[32];  // @64   bounding boxes + shape row offsets
   int8_t goal[32][2];     // @192  goal k is the target of movable k+1
   int8_t init[32][2];     // @256  initial positions
 };
+
+// the `off_small` entry of an object with bounding box w x h and shape rows `rows` (bit x of rows[r] = cell (x, r));
+// host side (the device packer in pw_generate.inc builds the same value from its grid rows)
+static inline uint64_t pw_small_board(const uint64_t* rows, int w, int h) {
+  if (w > 8 || h > 8) return 0;
+  uint64_t s = 0;
+  for (int r = 0; r < h; r++) s |= (rows[r] & 0xffull) << (8 * r);
+  return s;
+}
 
 #endif  // PW_FORMAT_H_

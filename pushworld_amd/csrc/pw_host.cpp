@@ -278,6 +278,11 @@ void pack_puzzle(const PwPuzzle& pz, PwPuzzleHeader* hdr, std::vector<uint8_t>& 
   hdr->n_mcells = static_cast<uint32_t>(mcells.size());
   if (mcells.empty()) mcells.push_back(0);
   hdr->off_mcells = append(blob, mcells) - base;
+
+  std::vector<uint64_t> small(N, 0);
+  for (int j = 0; j < N; j++)
+    small[j] = pw_small_board(shape_rows.data() + hdr->objtab[j].row_off, hdr->objtab[j].w, hdr->objtab[j].h);
+  hdr->off_small = append(blob, small) - base;
 }
 
 int copy_cells(const std::vector<PwCell>& v, int32_t* xy, int cap) {
@@ -461,7 +466,7 @@ struct PwSetFileHeader {
   uint8_t reserved[16];
 };
 static_assert(sizeof(PwSetFileHeader) == 64, "file header is 64 bytes");
-#define PW_SETFILE_VERSION 1u
+#define PW_SETFILE_VERSION 2u  // 2: PwPuzzleHeader::off_small
 
 static uint64_t fnv1a64(const void* data, size_t n, uint64_t h) {
   const uint8_t* p = static_cast<const uint8_t*>(data);
@@ -492,7 +497,8 @@ static const char* pw_validate_packed_puzzle(const PwPuzzleHeader& h, const uint
   }
   if (!inside(h.off_wall, 8ull * h.H, 8) || !inside(h.off_awall, 8ull * h.H, 8) ||
       !inside(h.off_shapes, 8ull * shape_rows, 8) || !inside(h.off_static, 4ull * h.W * h.H, 4) ||
-      !inside(h.off_mcells, 4ull * std::max<uint32_t>(h.n_mcells, 1u), 4) || h.n_mcells > 64u * 64u)
+      !inside(h.off_mcells, 4ull * std::max<uint32_t>(h.n_mcells, 1u), 4) || h.n_mcells > 64u * 64u ||
+      !inside(h.off_small, 8ull * h.N, 8))
     return "table offsets out of range";
   const uint64_t width_mask = h.W >= 64 ? ~0ull : ((1ull << h.W) - 1ull);
   const uint64_t* wall = reinterpret_cast<const uint64_t*>(blob + h.base + h.off_wall);
@@ -505,6 +511,8 @@ static const char* pw_validate_packed_puzzle(const PwPuzzleHeader& h, const uint
     const uint64_t m = o.w >= 64 ? ~0ull : ((1ull << o.w) - 1ull);
     for (int r = 0; r < o.h; r++)
       if (shapes[o.row_off + r] & ~m) return "shape rows reach outside the bounding box";
+    if (reinterpret_cast<const uint64_t*>(blob + h.base + h.off_small)[j] != pw_small_board(shapes + o.row_off, o.w, o.h))
+      return "small-object bitboards do not match the shape rows";
   }
   const uint32_t* mcells = reinterpret_cast<const uint32_t*>(blob + h.base + h.off_mcells);
   for (uint32_t i = 0; i < h.n_mcells; i++) {

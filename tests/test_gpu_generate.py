@@ -23,8 +23,8 @@ def _sections(header: bytes, blob: bytes):
     """(header with `base` zeroed, the puzzle's own bytes of the blob) of one packed puzzle"""
     base, = struct.unpack_from("<I", header, 0)
     W, H, N, G = header[4:8]
-    off_mcells, n_mcells = struct.unpack_from("<II", header, 24)
-    used = off_mcells + 4 * max(n_mcells, 1)
+    off_small, = struct.unpack_from("<I", header, 36)  # the last section: one uint64 per movable
+    used = off_small + 8 * N
     return b"\0\0\0\0" + header[4:], blob[base:base + used], (W, H, N, G)
 
 
