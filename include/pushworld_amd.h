@@ -201,10 +201,12 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_PAGE_LDS_PAD_KB 9   /* KiB of unused dynamic LDS per workgroup: caps the workgroups per CU, i.e. the width
                                       of the chip-wide write front (default 7 for uint8, 8 for float32 observations) */
 #define PW_OPT_STEP_LDS_TABLES 10   /* the lane-group step kernel copies the puzzle's wall / shape row bitboards into LDS first
-                                      and reads them from there: 0 automatic (launches of >= 4 steps, where it measured
-                                      5-18 % faster; one step per launch: no difference), 1 always, 2 never */
+                                      and reads them from there: 0 automatic (launches of >= 4 steps on sets with more than
+                                      16 movables per puzzle, where it measures ~7 % faster), 1 always, 2 never */
 #define PW_OPT_TUNED_NS 11          /* read-only: nanoseconds per render launch measured for the configuration the last
                                       pw_engine_tune_render kept (0 before the first call) */
+#define PW_OPT_STEP_WIDE_GROUPS 12   /* sets with 17..32 movables per puzzle (N_pad 32): 0 (default) 16 lanes per environment,
+                                      two movables per lane (4 environments per wavefront); 1: 32 lanes, one movable each */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

@@ -156,6 +156,7 @@ OPTIONS = {
     "page_lds_pad_kb": 9,
     "step_lds_tables": 10,
     "tuned_ns": 11,          # read-only
+    "step_wide_groups": 12,  # N_pad 32: 0 two movables per lane (16-lane groups), 1 32-lane groups
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1}
 

@@ -42,14 +42,18 @@ def _groups(golden):
 
 def _step_options(kernel):
     """engine options of a step-kernel flavour: "group" (default: row tables read from global memory for single
-    steps), "group-lds" (row tables staged in LDS, the default of multi-step rollouts), "lane", "wave"."""
+    steps; pools with more than 16 movables per puzzle: two per lane), "group-lds" (row tables staged in LDS, the
+    default of multi-step rollouts), "group-wide" (32-lane groups), "lane", "wave"."""
     if kernel == "group-lds":
         return {"step_kernel": "group", "step_lds_tables": 1}
+    if kernel == "group-wide":  # N_pad 32 pools: 32 lanes per environment instead of two movables per lane
+        return {"step_kernel": "group", "step_lds_tables": 2, "step_wide_groups": 1}
     return {"step_kernel": kernel, "step_lds_tables": 2}
 
 
 @pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
                                           ("bench", "group-lds"), ("tests", "group-lds"), ("l0", "group-lds"),
+                                          ("bench", "group-wide"),
                                           ("bench", "lane"), ("tests", "lane"), ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
@@ -108,7 +112,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "lane", "wave"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "lane", "wave"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
@@ -384,7 +388,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
                 assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "lane"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):
     """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's
