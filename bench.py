@@ -248,8 +248,9 @@ def main():
                     help="plumbing test on a 1-GPU box: all ranks on cuda:0, gloo for the counter reduction "
                          "(RCCL refuses two ranks on one device)")
     ap.add_argument("--fused", type=int, default=0, help="1: single fused step+render launch (engine option)")
-    ap.add_argument("--tune-allocations", type=int, default=6,
-                    help="candidate allocations of the observation buffer the tuner chooses among (VecPushWorld)")
+    ap.add_argument("--tune-allocations", type=int, default=16,
+                    help="at most this many candidate allocations of the observation buffer for the tuner (VecPushWorld stops at "
+                         "the first one of the fast class)")
     args = ap.parse_args()
     if args.obs is None:
         args.obs = "uint8" if args.config == "c3" else "none"
@@ -417,7 +418,9 @@ def main():
             # launch configuration of the page-ordered render kernel on rank 0 (pw_engine_tune_render at the first
             # reset: same bytes, the fastest of 16 page orders / occupancies for THIS observation buffer)
             "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
-                              "allocations_tried": args.tune_allocations, "page_order": eng.get_option("page_order"),
+                              "allocations_tried": len(vec.tuned_candidates_ms), "allocations_max": args.tune_allocations,
+                              "candidates_ms": [round(x, 4) for x in vec.tuned_candidates_ms],
+                              "page_order": eng.get_option("page_order"),
                               "page_run_log2": eng.get_option("page_run_log2"),
                               "page_lds_pad_kb": eng.get_option("page_lds_pad_kb")},
         },

@@ -49,10 +49,12 @@ class VecPushWorld:
         tune: auto-tune the launch configuration of the page-ordered render kernel on this environment's own
             observation buffer at the first ``reset`` (``pw_engine_tune_render``, a few dozen extra render launches
             once).  Default: on for observation buffers of 256 MB and more, where the choice is worth 5-15 %.
-        tune_allocations: with ``tune``: try this many allocations of the observation buffer and keep the one the
-            tuned render kernel is fastest on (the others are freed).  Buffers of identical size and alignment differ
-            by up to 8 % in what the kernel reaches on them -- it follows their physical backing -- so a long
-            training job can afford k allocations + k tuner runs (~0.1 s each at 3.8 GB) once.
+        tune_allocations: with ``tune``: try up to this many allocations of the observation buffer and keep the one
+            the tuned render kernel is fastest on (the others are freed); stops at the first one that is 6 % faster
+            than the slowest seen.  Buffers of identical size and alignment differ by up to 10 % in what the kernel
+            reaches on them -- it follows their physical backing, about one allocation in five is of the fast class
+             -- so a long training job can afford k allocations + k tuner runs (~0.1 s each at
+            3.8 GB) once.
         engine_options: ``pw_engine_set_option`` settings (``_capi.OPTIONS``), e.g. ``{"step_kernel": "lane"}`` --
             kernel selection for tests and A/B runs; results never depend on them.
     """
@@ -112,6 +114,7 @@ class VecPushWorld:
         self._tune_allocations = max(1, int(tune_allocations))
         self.tuned_config = None  # index returned by pw_engine_tune_render, once it ran
         self.tuned_ms = None      # milliseconds per render launch it measured for that configuration
+        self.tuned_candidates_ms = []  # the same for every candidate allocation it tried (tune_allocations)
 
         self.seed = int(seed)
         self.resample = resample is not False and resample is not None
@@ -160,17 +163,25 @@ class VecPushWorld:
         eng = self.engine
         keys = ("page_order", "page_run_log2", "page_lds_pad_kb")
         best = None
-        candidates = [(self._obs_storage, self.obs)]
-        for _ in range(self._tune_allocations - 1):
-            try:
-                candidates.append(eng.alloc_obs(self.num_envs))
-            except RuntimeError:  # out of memory: tune on the candidates there are
-                break
-        for storage, view in candidates:
+        candidates = []  # all kept alive until the choice is made: every new one lands on other physical memory
+        self.tuned_candidates_ms = []  # best launch time on every candidate buffer, in allocation order
+        for k in range(self._tune_allocations):
+            if k == 0:
+                storage, view = self._obs_storage, self.obs
+            else:
+                try:
+                    storage, view = eng.alloc_obs(self.num_envs)
+                except RuntimeError:  # out of memory: choose among the candidates there are
+                    break
+            candidates.append((storage, view))
             idx = eng.tune_render(self.puzzle_id, self.pos, storage)
             ns = eng.get_option("tuned_ns")
+            self.tuned_candidates_ms.append(ns * 1e-6)
             if best is None or ns < best[0]:
-                best = (ns, idx, tuple(eng.get_option(k) for k in keys), storage, view)
+                best = (ns, idx, tuple(eng.get_option(k_) for k_ in keys), storage, view)
+            # a buffer of the fast class shows as >= 6 % under the slowest one seen: no need to look further
+            if best[0] <= 0.94e6 * max(self.tuned_candidates_ms):
+                break
         ns, idx, cfg, storage, view = best
         for k, v in zip(keys, cfg):
             eng.set_option(k, v)

@@ -43,6 +43,8 @@ int vmm_alloc(int device, size_t bytes, size_t chunk, int mode, uint64_t seed, v
       s ^= s << 17;
       std::swap(order[i], order[s % (i + 1)]);
     }
+  } else if (mode == 4) {  // reverse creation order
+    for (size_t i = 0; i < n; i++) order[i] = n - 1 - i;
   } else if (mode == 3) {
     size_t k = 0;
     for (size_t i = 0; i < n; i += 2) order[k++] = i;

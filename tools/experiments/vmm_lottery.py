@@ -53,12 +53,13 @@ print("%-44s" % "buffer" + "".join("%14s" % n for n, _ in CFGS))
 ref = vec._obs_storage
 print("%-44s" % "torch allocation (engine's)" + "".join("%14.4f" % timed(ref.data_ptr(), c) for _, c in CFGS), flush=True)
 MB = 1 << 20
-for mode, chunk, seed, label in [(0, 0, 0, "vmm: one chunk"), (0, 0, 0, "vmm: one chunk (again)"),
-                                 (1, 64 * MB, 0, "vmm: 64 MB chunks in order"), (2, 64 * MB, 1, "vmm: 64 MB chunks permuted"),
-                                 (1, 512 * MB, 0, "vmm: 512 MB chunks in order"), (2, 512 * MB, 1, "vmm: 512 MB chunks permuted"),
-                                 (3, 64 * MB, 0, "vmm: 64 MB, evens then odds"), (1, 2 * MB, 0, "vmm: 2 MB chunks in order"),
-                                 (2, 2 * MB, 1, "vmm: 2 MB chunks permuted"), (2, 2 * MB, 2, "vmm: 2 MB chunks permuted (seed 2)"),
-                                 (3, 2 * MB, 0, "vmm: 2 MB chunks, evens then odds")]:
+CASES = [(0, 0, 0, "vmm: one chunk")] * 2
+for mb in (2, 64, 256, 512):
+    CASES += [(1, mb * MB, 0, "vmm: %d MB chunks in order" % mb)] * 2 + [(4, mb * MB, 0, "vmm: %d MB chunks reversed" % mb)] * 2
+CASES += [(2, 64 * MB, 1, "vmm: 64 MB chunks permuted"), (3, 64 * MB, 0, "vmm: 64 MB, evens then odds")]
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if sys.argv[1] in c[3]]
+for mode, chunk, seed, label in CASES:
     p, h = ctypes.c_void_p(), ctypes.c_void_p()
     n = vmm.vmm_alloc(0, nbytes, chunk, mode, seed, ctypes.byref(p), ctypes.byref(h))
     if n <= 0:
