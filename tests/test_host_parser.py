@@ -253,6 +253,7 @@ def test_packed_set_file_round_trip_and_rejects_corruption(golden, tmp_path):
     base0, = struct.unpack_from("<I", raw, H0)
     W0, Hh0, N0, G0 = raw[H0 + 4:H0 + 8]
     off_static0, off_mcells0, n_mcells0 = struct.unpack_from("<III", raw, H0 + 20)
+    off_small0, = struct.unpack_from("<I", raw, H0 + 36)
     assert n_mcells0 >= 1 and N0 >= 1
     blob_len = len(pset.blob())
 
@@ -271,6 +272,8 @@ def test_packed_set_file_round_trip_and_rejects_corruption(golden, tmp_path):
         "movable cell x": put(blob0 + base0 + off_mcells0, "<B", 200),               # mcells[0].cx >= w
         "static cell kind": put(blob0 + base0 + off_static0 + 1, "<B", 0x0F),        # kind 15
         "goal count": put(H0 + 7, "<B", N0),                                         # G >= N
+        "small-board section extent": put(H0 + 36, "<I", blob_len - base0),          # off_small at the blob's end
+        "small board != shape rows": put(blob0 + base0 + off_small0 + 7, "<B", 0x80),  # a cell the shape rows lack
         "zero width": put(H0 + 4, "<B", 0),
     }
     for what, patch in cases.items():
