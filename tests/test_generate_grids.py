@@ -1,6 +1,5 @@
 """CPU: the level-0 generator behind pw_generate_level0 (host instance of the function the kernel runs) -- recipe
 properties of generate.py:74-259, determinism, and the text form through the parser."""
-import numpy as np
 import pytest
 
 from pushworld_amd import _capi, generate

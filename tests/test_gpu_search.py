@@ -1,6 +1,5 @@
 """GPU breadth-first frontier services (pw_search_*) against a sequential FIFO
 breadth-first search over the oracle: identical state numbering, links, layers and plans."""
-import os
 from collections import deque
 
 import numpy as np
