@@ -49,12 +49,14 @@ class VecPushWorld:
         tune: auto-tune the launch configuration of the page-ordered render kernel on this environment's own
             observation buffer at the first ``reset`` (``pw_engine_tune_render``, a few dozen extra render launches
             once).  Default: on for observation buffers of 256 MB and more, where the choice is worth 5-15 %.
-        tune_allocations: with ``tune``: try up to this many allocations of the observation buffer and keep the one
+        tune_allocations: with ``tune`` (default: up to 8, within a quarter of the free device memory): try up to this
+            many allocations of the observation buffer and keep the one
             the tuned render kernel is fastest on (the others are freed); stops at the first one that is 6 % faster
             than the slowest seen.  Buffers of identical size and alignment differ by up to 10 % in what the kernel
             reaches on them -- it follows their physical backing, about one allocation in five is of the fast class
              -- so a long training job can afford k allocations + k tuner runs (~0.1 s each at
-            3.8 GB) once.
+            3.8 GB) once.  ``self.obs`` is bound to the chosen buffer at the first ``reset``: take the observation
+            tensor from the return values of ``reset`` / ``step`` (or read ``self.obs`` afterwards).
         engine_options: ``pw_engine_set_option`` settings (``_capi.OPTIONS``), e.g. ``{"step_kernel": "lane"}`` --
             kernel selection for tests and A/B runs; results never depend on them.
     """
@@ -65,7 +67,7 @@ class VecPushWorld:
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
                  autoreset: bool = False, fused: bool = True, resample=False, seed: int = 0,
                  incremental: bool = False, engine_options: Optional[dict] = None, tune: Optional[bool] = None,
-                 tune_allocations: int = 1):
+                 tune_allocations: Optional[int] = None):
         if observation not in ("uint8", "float32", None):
             raise ValueError("observation must be 'uint8', 'float32' or None")
         dev = default_device_index() if device is None else int(device)
@@ -111,6 +113,11 @@ class VecPushWorld:
         if tune is None:
             tune = self.obs is not None and self.num_envs * self.engine.obs_stride >= (256 << 20)
         self._tune_pending = bool(tune) and self.obs is not None
+        if tune_allocations is None:  # as many as fit into a quarter of the free device memory, at most 8
+            tune_allocations = 1
+            if self._tune_pending:
+                free, _ = torch.cuda.mem_get_info(self.device)
+                tune_allocations = min(8, max(1, int(free // 4 // (self.num_envs * self.engine.obs_stride))))
         self._tune_allocations = max(1, int(tune_allocations))
         self.tuned_config = None  # index returned by pw_engine_tune_render, once it ran
         self.tuned_ms = None      # milliseconds per render launch it measured for that configuration
