@@ -24,14 +24,20 @@ def main():
     ap.add_argument("--ppc", type=int, default=3)
     ap.add_argument("--bw", type=int, default=1)
     ap.add_argument("--obs", default="uint8")
+    ap.add_argument("--config", default="c3", choices=("c3", "c4"))
     args = ap.parse_args()
-    paths = bench.level1_paths()
     B = args.envs
-    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
-    # fused=True: the bench's path (pw_step_render: the step kernel leaves the page records, no pre-pass); the tuner's
-    # trial launches at reset() run under their own kernel symbol (pw_render_page_kernel<T, 1>)
-    vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, border_width=args.bw,
-                       pixels_per_cell=args.ppc, observation=args.obs, device=0, autoreset=True, fused=True)
+    if args.config == "c4":  # rank 0's shard of the 8-rank assignment, exactly as bench.py --config c4 builds it
+        wl = argparse.Namespace(envs_per_gpu=B, obs=args.obs, config="c4", max_steps=200, bw=args.bw, ppc=args.ppc,
+                                tune_allocations=1)
+        vec = bench.build_workload(wl, 0, 8, 0)["vec"]
+    else:
+        paths = bench.level1_paths()
+        ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+        # fused=True: the bench's path (pw_step_render: the step kernel leaves the page records, no pre-pass); the
+        # tuner's trial launches at reset() run under their own kernel symbol (pw_render_page_kernel<T, 1>)
+        vec = VecPushWorld([PushWorldPuzzle(p) for p in paths], B, puzzle_ids=ids, max_steps=200, border_width=args.bw,
+                           pixels_per_cell=args.ppc, observation=args.obs, device=0, autoreset=True, fused=True)
     vec.reset()
     gen = torch.Generator(device=vec.device)
     gen.manual_seed(1)
