@@ -36,6 +36,40 @@ __global__ __launch_bounds__(64) void probe_multi_kernel(MultiArgs a) {
   for (int i = 0; i < 4; i++) __builtin_nontemporal_store(v, p + 64 * i);
 }
 
+// P parts of `per` pages each; XCD k owns the parts k, k + 8, ... and interleaves them page by page (P = 8: the eighths
+// order; P = 64: every XCD keeps 8 write fronts going)
+__global__ __launch_bounds__(64) void probe_parts_kernel(uint8_t* base, uint32_t per, uint32_t m, uint32_t n_pages) {
+  const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3;  // j-th page of XCD k
+  const uint32_t part = k + 8u * (j % m), off = j / m;
+  const uint32_t page = part * per + off;
+  if (off >= per || page >= n_pages) return;
+  u32x4* p = reinterpret_cast<u32x4*>(base + static_cast<size_t>(page) * 4096) + threadIdx.x;
+  const u32x4 v = {page, k, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < 4; i++) __builtin_nontemporal_store(v, p + 64 * i);
+}
+
+extern "C" int xcd_probe_parts(void* base, uint32_t n_pages, uint32_t parts, int reps, int lds_pad, float* ms_out) {
+  if (parts < 8 || parts % 8) return -1;
+  const uint32_t m = parts / 8, per = (n_pages + parts - 1) / parts;
+  const uint32_t grid = per * m * 8;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(probe_parts_kernel, dim3(grid), dim3(64), lds_pad, 0, static_cast<uint8_t*>(base), per, m, n_pages);
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(probe_parts_kernel, dim3(grid), dim3(64), lds_pad, 0, static_cast<uint8_t*>(base), per, m, n_pages);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int xcd_probe_multi(void* const* base, const uint32_t* pages, int reps, int lds_pad, float* ms_out) {
   MultiArgs a;
   uint32_t most = 0;
