@@ -49,9 +49,16 @@ __global__ __launch_bounds__(64) void probe_parts_kernel(uint8_t* base, uint32_t
   for (int i = 0; i < 4; i++) __builtin_nontemporal_store(v, p + 64 * i);
 }
 
+extern "C" int xcd_probe_parts_per(void* base, uint32_t n_pages, uint32_t parts, uint32_t per, int reps, int lds_pad, float* ms_out);
+
 extern "C" int xcd_probe_parts(void* base, uint32_t n_pages, uint32_t parts, int reps, int lds_pad, float* ms_out) {
+  return xcd_probe_parts_per(base, n_pages, parts, (n_pages + parts - 1) / parts, reps, lds_pad, ms_out);
+}
+
+// the same with a chosen part size (pages); pages beyond parts * per are not written (callers keep the loss tiny)
+extern "C" int xcd_probe_parts_per(void* base, uint32_t n_pages, uint32_t parts, uint32_t per, int reps, int lds_pad, float* ms_out) {
   if (parts < 8 || parts % 8) return -1;
-  const uint32_t m = parts / 8, per = (n_pages + parts - 1) / parts;
+  const uint32_t m = parts / 8;
   const uint32_t grid = per * m * 8;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
