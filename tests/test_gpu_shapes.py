@@ -129,3 +129,53 @@ def test_random_shapes_step_matches_oracle(torch_mod, n_movables, options):
         got = got[:, :n_movables, 0] * 10000 + got[:, :n_movables, 1]
         bad = np.nonzero((got != want[:, a]).any(axis=1))[0]
         assert bad.size == 0, (a, states[bad[0]].tolist(), got[bad[0]].tolist(), want[bad[0], a].tolist())
+
+
+def test_maximum_sizes_64x64_grid_32_movables(torch_mod):
+    """The engine's limits: a 62 x 62 file grid (64 x 64 with the border walls) with 32 movables --
+    successors, moved masks and goal flags of random states, the step kernels and the uint8 / float32 observations
+    (the 64-row frame is where the row bitboards and the page records run out of bits) against the oracle; one cell or
+    one movable more is a ValueError."""
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    torch = torch_mod
+    rng = np.random.default_rng(5)
+    text = random_puzzle(rng, 32, size=62)
+    pz = PushWorldPuzzle(text=text, order="cpp")
+    assert pz.dimensions == (64, 64) and pz.num_movables == 32
+    oz = c_oracle.COraclePuzzle(text, order="cpp")
+    states = random_states(rng, pz, 4000)
+    s, m, g = pz.expand4(states)
+    ws, wm, wg = c_oracle.expand4_batch(oz, states)
+    assert (s.cpu().numpy() == ws).all() and (m.cpu().numpy().astype(np.uint32) == wm).all() and (g.cpu().numpy() == wg).all()
+
+    pzp = PushWorldPuzzle(text=text)
+    ozp = c_oracle.COraclePuzzle(text, order="python")
+    B = 512
+    st = random_states(rng, pzp, B)
+    want, _, _ = c_oracle.expand4_batch(ozp, st)
+    base = np.zeros((B, 32, 2), np.int8)
+    base[:, :, 0] = st // 10000
+    base[:, :, 1] = st % 10000
+    for options in ({}, {"step_wide_groups": 1}, {"step_kernel": "lane"}, {"step_kernel": "wave"}):
+        vec = VecPushWorld([pzp], B, observation=None, device=0, engine_options=options)
+        vec.reset()
+        for a in range(4):
+            vec.set_states(base)
+            vec.step(torch.full((B,), a, dtype=torch.uint8, device=vec.device))
+            got = vec.pos.cpu().numpy().astype(np.int32)
+            assert (got[:, :, 0] * 10000 + got[:, :, 1] == want[:, a]).all(), (options, a)
+    for obs, ppc, bw in (("uint8", 3, 1), ("float32", 3, 1), ("uint8", 5, 2)):
+        vec = VecPushWorld([pzp], 64, observation=obs, pixels_per_cell=ppc, border_width=bw, device=0, tune=False)
+        vec.reset()
+        vec.set_states(base[:64])
+        img = vec.render().cpu().numpy()
+        wantimg = c_oracle.observe_batch([ozp], np.zeros(64, np.int32), base[:64], np.arange(64), 64, 64, ppc, bw,
+                                         "f32" if obs == "float32" else "u8")
+        assert (img == wantimg).all(), (obs, ppc, bw)
+
+    for size, n in ((63, 5), (20, 33)):
+        with pytest.raises(ValueError):
+            PushWorldPuzzle(text=random_puzzle(rng, n, size=size))._puzzle_set
