@@ -12,6 +12,8 @@
  *   - extern "C", plain pointers and sizes, no C++ / torch types.
  *   - every function returns 0 on success or a negative PW_E* code; no C++
  *     exception crosses the ABI; pw_last_error() returns a thread-local message.
+ *   - an empty batch (batch / num_states <= 0, num_steps == 0) is a no-op that returns PW_OK without looking at
+ *     the buffer pointers (an empty tensor's data pointer is NULL);
  *   - "device pointers" are caller-owned HBM buffers (e.g. tensor.data_ptr());
  *     `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
  *     are asynchronous on that stream; the engine never allocates per call (one exception:

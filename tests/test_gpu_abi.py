@@ -220,3 +220,53 @@ def test_entry_points_leave_the_current_device_alone(torch_mod, golden):
         bfs.expand()
         assert bfs.total_states > 1 and torch.cuda.current_device() == 0
         bfs.close()
+
+
+@pytest.mark.parametrize("kernel", ["group", "lane", "wave"])
+def test_puzzle_without_goals_terminates_at_once(torch_mod, kernel):
+    """A puzzle without goals: `is_goal_state` is vacuously true (puzzle.py:409-411, all() of nothing), so every step
+    terminates with reward 10 -- also after the autoreset -- exactly as the oracle's restatement does."""
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    torch = torch_mod
+    text = "\n".join(["  ".join(r) for r in (["A", ".", "M0", "."], [".", ".", ".", "W"], ["M1", ".", ".", "."])])
+    pz = PushWorldPuzzle(text=text)
+    oz = c_oracle.COraclePuzzle(text, order="python")
+    assert len(pz.goal_state) == 0 and pz.is_goal_state(pz.initial_state)
+    B, T = 64, 12
+    acts = np.random.default_rng(3).integers(0, 4, (T, B)).astype(np.uint8)
+    pos, rew, term, trunc, steps = c_oracle.rollout_trace([oz], np.zeros(B, np.int32), acts, 5, True, 4)
+    vec = VecPushWorld([pz], B, observation=None, max_steps=5, autoreset=True, device=0, engine_options={"step_kernel": kernel})
+    vec.reset()
+    dev = torch.as_tensor(acts).to(vec.device)
+    for t in range(T):
+        _, r, te, tr = vec.step(dev[t])
+        assert (vec.pos.cpu().numpy() == pos[t]).all(), t
+        assert (r.cpu().numpy().view(np.uint64) == rew[t].view(np.uint64)).all(), t
+        assert (te.cpu().numpy() == term[t]).all() and (tr.cpu().numpy() == trunc[t]).all(), t
+    assert (term[0] == 1).all() and (rew[0] == 10.0).all() and (term[1] == 0).all()  # step, autoreset, step, ...
+
+
+def test_empty_batches_and_zero_steps_are_no_ops(torch_mod):
+    """batch = 0 / num_steps = 0 / an empty frontier: PW_OK, nothing launched, nothing touched."""
+    from pushworld_amd import _capi
+
+    torch = torch_mod
+    vec = _level1_vec(B=64, observation=None)
+    vec.reset()
+    before = vec.pos.clone()
+    eng = vec.engine
+    empty8 = torch.zeros((0,), dtype=torch.uint8, device=vec.device)
+    z = lambda t: t[:0]  # noqa: E731
+    eng.step(z(vec.puzzle_id), empty8, z(vec.pos), z(vec.steps), z(vec.reward), z(vec.dgoals), z(vec.terminated),
+             z(vec.truncated), 0)
+    vec.rollout(torch.zeros((0, 64), dtype=torch.uint8, device=vec.device))
+    torch.cuda.synchronize()
+    assert torch.equal(vec.pos, before) and int(vec.steps.sum()) == 0
+    eng.validate(z(vec.puzzle_id), z(vec.pos))  # nothing to complain about
+    eng.reset(z(vec.puzzle_id), z(vec.pos), z(vec.steps), z(vec.terminated), z(vec.truncated))
+    assert _capi.lib.pw_expand4(eng.handle, 0, None, None, None, None, 0, None) == _capi.PW_OK
+    assert _capi.lib.pw_expand4(eng.handle, 0, None, None, None, None, 5, None) == _capi.PW_EINVAL  # 5 states, no buffers
+    assert _capi.lib.pw_step(None, None, None, None, None, None, None, None, None, 0, 0, None) == _capi.PW_EINVAL  # no engine
