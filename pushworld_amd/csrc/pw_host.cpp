@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
 #include <set>
 
 #include "pw_device_guard.h"
@@ -27,6 +28,25 @@ void pw_set_error(const std::string& msg) { g_last_error = msg; }
 int pw_fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
+}
+
+int pw_current_exception() noexcept {
+  try {
+    try {
+      throw;
+    } catch (const std::bad_alloc&) {
+      g_last_error = "out of host memory";
+      return PW_ENOMEM;
+    } catch (const std::exception& ex) {
+      g_last_error = std::string("unexpected error: ") + ex.what();
+      return PW_EINVAL;
+    } catch (...) {
+      g_last_error = "unexpected error";
+      return PW_EINVAL;
+    }
+  } catch (...) {  // the message itself could not be stored
+    return PW_ENOMEM;
+  }
 }
 
 namespace {
@@ -321,14 +341,16 @@ extern "C" {
 const char* pw_last_error(void) { return g_last_error.c_str(); }
 int pw_abi_version(void) { return PW_ABI_VERSION; }
 
-int pw_device_count(void) {
+int pw_device_count(void) try {
   int n = 0;
   hipError_t err = hipGetDeviceCount(&n);
   if (err != hipSuccess) return pw_fail(PW_EDEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(err));
   return n;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_parse(const char* text, size_t len, int order, PwPuzzle** out) {
+int pw_puzzle_parse(const char* text, size_t len, int order, PwPuzzle** out) try {
   if (!text || !out) return pw_fail(PW_EINVAL, "null argument");
   PwPuzzle* pz = new (std::nothrow) PwPuzzle();
   if (!pz) return pw_fail(PW_ENOMEM, "out of memory");
@@ -344,11 +366,13 @@ int pw_puzzle_parse(const char* text, size_t len, int order, PwPuzzle** out) {
   }
   *out = pz;
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
 void pw_puzzle_destroy(PwPuzzle* p) { delete p; }
 
-int pw_puzzle_info(const PwPuzzle* p, PwPuzzleInfo* info) {
+int pw_puzzle_info(const PwPuzzle* p, PwPuzzleInfo* info) try {
   if (!p || !info) return pw_fail(PW_EINVAL, "null argument");
   info->width = p->width;
   info->height = p->height;
@@ -359,41 +383,55 @@ int pw_puzzle_info(const PwPuzzle* p, PwPuzzleInfo* info) {
   info->has_agent_walls = p->has_agent_walls ? 1 : 0;
   info->order = p->order;
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_initial_state(const PwPuzzle* p, int32_t* xy) {
+int pw_puzzle_initial_state(const PwPuzzle* p, int32_t* xy) try {
   if (!p || !xy) return pw_fail(PW_EINVAL, "null argument");
   copy_cells(p->initial, xy, static_cast<int>(p->initial.size()));
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_goal_state(const PwPuzzle* p, int32_t* xy) {
+int pw_puzzle_goal_state(const PwPuzzle* p, int32_t* xy) try {
   if (!p) return pw_fail(PW_EINVAL, "null argument");
   copy_cells(p->goal, xy, static_cast<int>(p->goal.size()));
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_object_cells(const PwPuzzle* p, int obj, int32_t* xy, int cap) {
+int pw_puzzle_object_cells(const PwPuzzle* p, int obj, int32_t* xy, int cap) try {
   if (!p || obj < 0 || obj >= static_cast<int>(p->shapes.size())) return pw_fail(PW_EINVAL, "bad object index");
   return copy_cells(p->shapes[obj], xy, cap);
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_goal_cells(const PwPuzzle* p, int goal, int32_t* xy, int cap) {
+int pw_puzzle_goal_cells(const PwPuzzle* p, int goal, int32_t* xy, int cap) try {
   if (!p || goal < 0 || goal >= static_cast<int>(p->goal_shapes.size())) return pw_fail(PW_EINVAL, "bad goal index");
   return copy_cells(p->goal_shapes[goal], xy, cap);
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_wall_cells(const PwPuzzle* p, int32_t* xy, int cap) {
+int pw_puzzle_wall_cells(const PwPuzzle* p, int32_t* xy, int cap) try {
   if (!p) return pw_fail(PW_EINVAL, "null argument");
   return copy_cells(p->walls, xy, cap);
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_agent_wall_cells(const PwPuzzle* p, int32_t* xy, int cap) {
+int pw_puzzle_agent_wall_cells(const PwPuzzle* p, int32_t* xy, int cap) try {
   if (!p) return pw_fail(PW_EINVAL, "null argument");
   return copy_cells(p->agent_walls, xy, cap);
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzle_object_name(const PwPuzzle* p, int obj, char* buf, int cap) {
+int pw_puzzle_object_name(const PwPuzzle* p, int obj, char* buf, int cap) try {
   if (!p || obj < 0 || obj >= static_cast<int>(p->names.size())) return pw_fail(PW_EINVAL, "bad object index");
   const std::string& s = p->names[obj];
   if (buf && cap > 0) {
@@ -402,9 +440,11 @@ int pw_puzzle_object_name(const PwPuzzle* p, int obj, char* buf, int cap) {
     buf[n] = 0;
   }
   return static_cast<int>(s.size());
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzleset_create(const PwPuzzle* const* puzzles, int n, int device, PwPuzzleSet** out) {
+int pw_puzzleset_create(const PwPuzzle* const* puzzles, int n, int device, PwPuzzleSet** out) try {
   if (!puzzles || !out || n <= 0) return pw_fail(PW_EINVAL, "empty puzzle set");
   PwPuzzleSet* s = new (std::nothrow) PwPuzzleSet();
   if (!s) return pw_fail(PW_ENOMEM, "out of memory");
@@ -425,6 +465,8 @@ int pw_puzzleset_create(const PwPuzzle* const* puzzles, int n, int device, PwPuz
   if (int rc = upload_set(s)) return rc;
   *out = s;
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
 void pw_puzzleset_destroy(PwPuzzleSet* s) {
@@ -434,21 +476,27 @@ void pw_puzzleset_destroy(PwPuzzleSet* s) {
   delete s;
 }
 
-int pw_puzzleset_size(const PwPuzzleSet* s) { return s ? s->count : pw_fail(PW_EINVAL, "null set"); }
+int pw_puzzleset_size(const PwPuzzleSet* s) try { return s ? s->count : pw_fail(PW_EINVAL, "null set"); } catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
+}
 
-int pw_puzzleset_max_dims(const PwPuzzleSet* s, int* max_w, int* max_h, int* max_n) {
+int pw_puzzleset_max_dims(const PwPuzzleSet* s, int* max_w, int* max_h, int* max_n) try {
   if (!s) return pw_fail(PW_EINVAL, "null set");
   if (max_w) *max_w = s->max_w;
   if (max_h) *max_h = s->max_h;
   if (max_n) *max_n = s->max_n;
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzleset_blob(const PwPuzzleSet* s, const void** data, size_t* bytes) {
+int pw_puzzleset_blob(const PwPuzzleSet* s, const void** data, size_t* bytes) try {
   if (!s || !data || !bytes) return pw_fail(PW_EINVAL, "null argument");
   *data = s->blob.data();
   *bytes = s->blob.size();
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
 }  // extern "C"
@@ -528,7 +576,7 @@ static const char* pw_validate_packed_puzzle(const PwPuzzleHeader& h, const uint
 
 extern "C" {
 
-int pw_puzzleset_save(const PwPuzzleSet* s, const char* path) {
+int pw_puzzleset_save(const PwPuzzleSet* s, const char* path) try {
   if (!s || !path) return pw_fail(PW_EINVAL, "null argument");
   PwSetFileHeader fh;
   std::memset(&fh, 0, sizeof(fh));
@@ -548,9 +596,11 @@ int pw_puzzleset_save(const PwPuzzleSet* s, const char* path) {
             (s->blob.empty() || std::fwrite(s->blob.data(), s->blob.size(), 1, f) == 1);
   ok = (std::fclose(f) == 0) && ok;
   return ok ? PW_OK : pw_fail(PW_EINVAL, std::string("short write: ") + path);
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
-int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) {
+int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) try {
   if (!path || !out) return pw_fail(PW_EINVAL, "null argument");
   FILE* f = std::fopen(path, "rb");
   if (!f) return pw_fail(PW_EINVAL, std::string("cannot open: ") + path);
@@ -565,6 +615,13 @@ int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) {
   if (fh.count <= 0 || fh.blob_bytes % 16 != 0 || fh.blob_bytes > (1ull << 34) || fh.max_w > PW_MAX_DIM ||
       fh.max_h > PW_MAX_DIM || fh.max_n > PW_MAX_OBJECTS)
     return bad("corrupt file header");
+  {  // the sizes in the header must be the file's: nothing is allocated on the word of a crafted count
+    const uint64_t want = sizeof(fh) + static_cast<uint64_t>(fh.count) * sizeof(PwPuzzleHeader) + fh.blob_bytes;
+    if (std::fseek(f, 0, SEEK_END) != 0) return bad("cannot seek");
+    const long size = std::ftell(f);
+    if (size < 0 || static_cast<uint64_t>(size) != want) return bad(static_cast<uint64_t>(size) < want ? "truncated file" : "trailing bytes");
+    if (std::fseek(f, static_cast<long>(sizeof(fh)), SEEK_SET) != 0) return bad("cannot seek");
+  }
   PwPuzzleSet* s = new (std::nothrow) PwPuzzleSet();
   if (!s) {
     std::fclose(f);
@@ -596,6 +653,8 @@ int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) {
   if (int rc = upload_set(s)) return rc;
   *out = s;
   return PW_OK;
+} catch (...) {
+  return pw_current_exception();  // nothing C++ leaves the C ABI
 }
 
 }  // extern "C"

@@ -38,6 +38,10 @@ struct PwPuzzleSet {
 
 void pw_set_error(const std::string& msg);
 int pw_fail(int code, const std::string& msg);
+// Inside a catch (...) handler: the status code of the exception in flight (std::bad_alloc -> PW_ENOMEM, anything
+// else PW_EINVAL with its what()).  Every extern "C" entry point is a function-try-block that ends in it, so that
+// no C++ exception crosses the C ABI (host vectors and strings are the only things that can throw).
+int pw_current_exception() noexcept;
 
 // Makes `device` the calling thread's current HIP device for the lifetime of the guard and restores the caller's
 // device afterwards: no entry point of the C ABI changes the caller's current device (and therefore

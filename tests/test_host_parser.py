@@ -272,6 +272,8 @@ def test_packed_set_file_round_trip_and_rejects_corruption(golden, tmp_path):
         "movable cell x": put(blob0 + base0 + off_mcells0, "<B", 200),               # mcells[0].cx >= w
         "static cell kind": put(blob0 + base0 + off_static0 + 1, "<B", 0x0F),        # kind 15
         "goal count": put(H0 + 7, "<B", N0),                                         # G >= N
+        "puzzle count beyond the file": put(16, "<i", 1 << 30),                      # nothing is allocated on its word
+        "blob size beyond the file": put(32, "<Q", 1 << 33),
         "small-board section extent": put(H0 + 36, "<I", blob_len - base0),          # off_small at the blob's end
         "small board != shape rows": put(blob0 + base0 + off_small0 + 7, "<B", 0x80),  # a cell the shape rows lack
         "zero width": put(H0 + 4, "<B", 0),
