@@ -1,0 +1,45 @@
+"""CPU: the product never reaches the oracle and has no CPU fallback.
+
+* nothing under pushworld_amd/ imports (or even names) the oracle package: only tests/, __graft_entry__.smoke() and
+  bench.py's cpu_baseline legs may;
+* without the HIP library the package fails at import with an ImportError that says so."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|\boracle\.(pw_oracle|c_oracle|py_bench)\b|libpw_oracle", re.M)
+    offenders = []
+    for base, _, files in os.walk(os.path.join(ROOT, "pushworld_amd")):
+        for name in files:
+            if name.endswith((".py", ".cpp", ".hip", ".inc", ".h")):
+                with open(os.path.join(base, name), errors="replace") as f:
+                    if pat.search(f.read()):
+                        offenders.append(os.path.join(base, name))
+    assert not offenders, offenders
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        src = f.read()
+    # bench.py: the oracle only inside the two CPU-baseline functions
+    for m in re.finditer(r"^\s*from oracle import \w+", src, re.M):
+        head = src[:m.start()]
+        fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
+        assert fn in ("cpu_baseline", "python_env_baseline"), fn
+
+
+def test_missing_library_is_an_import_error_not_a_fallback(tmp_path):
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import os\n"
+        "os.environ['PUSHWORLD_AMD_LIB'] = %r\n"
+        "try:\n"
+        "    import pushworld_amd._capi\n"
+        "except ImportError as e:\n"
+        "    assert 'no CPU fallback' in str(e), e\n"
+        "    print('IMPORT_ERROR_OK')\n"
+    ) % (ROOT, str(tmp_path / "nowhere" / "libpushworld_amd.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "IMPORT_ERROR_OK" in out.stdout, out.stdout + out.stderr
