@@ -77,6 +77,72 @@ extern "C" int xcd_probe_parts_per(void* base, uint32_t n_pages, uint32_t parts,
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// the eighths order as a COPY: every page is first read from a small, cache-resident source (`src_pages` pages, wrapped),
+// like the render kernel reads its static images, then stored; mode 1: load all four chunks, then store; mode 2: two
+// pages per workgroup, the second page's loads issued before the first page's stores
+__global__ __launch_bounds__(64) void probe_copy_kernel(uint8_t* base, const uint8_t* src, uint32_t src_pages, uint32_t per,
+                                                        uint32_t n_pages, int mode) {
+  const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  if (mode == 2) {
+    const uint32_t o0 = 2 * j, o1 = 2 * j + 1;
+    if (o0 >= per) return;
+    const uint32_t p0 = k * per + o0, p1 = k * per + o1;
+    if (p0 >= n_pages) return;
+    const bool two = o1 < per && p1 < n_pages;
+    const u32x4* s0 = reinterpret_cast<const u32x4*>(src + static_cast<size_t>(p0 % src_pages) * 4096) + threadIdx.x;
+    const u32x4* s1 = reinterpret_cast<const u32x4*>(src + static_cast<size_t>(p1 % src_pages) * 4096) + threadIdx.x;
+    u32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = s0[64 * i];
+    if (two) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) b[i] = s1[64 * i];
+    }
+    u32x4* d0 = reinterpret_cast<u32x4*>(base + static_cast<size_t>(p0) * 4096) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) __builtin_nontemporal_store(a[i], d0 + 64 * i);
+    if (two) {
+      u32x4* d1 = reinterpret_cast<u32x4*>(base + static_cast<size_t>(p1) * 4096) + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < 4; i++) __builtin_nontemporal_store(b[i], d1 + 64 * i);
+    }
+    return;
+  }
+  if (j >= per) return;
+  const uint32_t page = k * per + j;
+  if (page >= n_pages) return;
+  const u32x4* s = reinterpret_cast<const u32x4*>(src + static_cast<size_t>(page % src_pages) * 4096) + threadIdx.x;
+  u32x4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = s[64 * i];
+  u32x4* d = reinterpret_cast<u32x4*>(base + static_cast<size_t>(page) * 4096) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) __builtin_nontemporal_store(v[i], d + 64 * i);
+}
+
+extern "C" int xcd_probe_copy(void* base, const void* src, uint32_t src_pages, uint32_t n_pages, int mode, int reps,
+                              int lds_pad, float* ms_out) {
+  const uint32_t per = (n_pages + 7) / 8;
+  const uint32_t grid = (mode == 2 ? (per + 1) / 2 : per) * 8;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(grid), dim3(64), lds_pad, 0, static_cast<uint8_t*>(base),
+                     static_cast<const uint8_t*>(src), src_pages, per, n_pages, mode);
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(grid), dim3(64), lds_pad, 0, static_cast<uint8_t*>(base),
+                       static_cast<const uint8_t*>(src), src_pages, per, n_pages, mode);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int xcd_probe_multi(void* const* base, const uint32_t* pages, int reps, int lds_pad, float* ms_out) {
   MultiArgs a;
   uint32_t most = 0;
