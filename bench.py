@@ -248,9 +248,9 @@ def main():
                     help="plumbing test on a 1-GPU box: all ranks on cuda:0, gloo for the counter reduction "
                          "(RCCL refuses two ranks on one device)")
     ap.add_argument("--fused", type=int, default=0, help="1: single fused step+render launch (engine option)")
-    ap.add_argument("--tune-allocations", type=int, default=16,
-                    help="at most this many candidate allocations of the observation buffer for the tuner (VecPushWorld stops at "
-                         "the first one of the fast class)")
+    ap.add_argument("--tune-allocations", type=int, default=None,
+                    help="at most this many candidate allocations of the library-owned observation buffer (pw_obs_alloc_tuned "
+                         "keeps the first one of the fast class); default: the product default of VecPushWorld")
     args = ap.parse_args()
     if args.obs is None:
         args.obs = "uint8" if args.config == "c3" else "none"
@@ -418,7 +418,11 @@ def main():
             # launch configuration of the page-ordered render kernel on rank 0 (pw_engine_tune_render at the first
             # reset: same bytes, the fastest of 16 page orders / occupancies for THIS observation buffer)
             "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
-                              "allocations_tried": len(vec.tuned_candidates_ms), "allocations_max": args.tune_allocations,
+                              "allocations_tried": len(vec.tuned_candidates_ms),
+                              "allocations_max": args.tune_allocations if args.tune_allocations is not None else "product default (<= 4)",
+                              "allocator": "pw_obs_alloc_tuned (HIP virtual-memory chunks; losers released to the device)",
+                              "torch_reserved_bytes": int(torch.cuda.memory_reserved(dev)),
+                              "page_load_all": eng.get_option("page_load_all"),
                               "candidates_ms": [round(x, 4) for x in vec.tuned_candidates_ms],
                               "page_order": eng.get_option("page_order"),
                               "page_run_log2": eng.get_option("page_run_log2"),

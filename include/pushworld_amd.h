@@ -16,8 +16,11 @@
  *     the buffer pointers (an empty tensor's data pointer is NULL);
  *   - "device pointers" are caller-owned HBM buffers (e.g. tensor.data_ptr());
  *     `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
- *     are asynchronous on that stream; the engine never allocates per call (one exception:
- *     pw_step_render_delta allocates a 4 B / environment scratch on first use or batch growth).
+ *     are asynchronous on that stream; the engine never allocates per call, with two exceptions on FIRST USE OR
+ *     BATCH GROWTH only: the page-ordered render (pw_render / pw_step_render) keeps a 16 B / environment record
+ *     array, pw_step_render_delta a 4 B / environment one.  They are engine-owned scratch written and read by the
+ *     kernels of one call, so all calls on one engine must go to ONE stream (or be event-ordered by the caller), and
+ *     the first call of a batch size must not sit inside a graph capture (pw_obs_alloc allocates the records up front).
  *   - no entry point changes the calling thread's current HIP device: everything an engine /
  *     set / search allocates or launches lands on the device of its puzzle set, and the
  *     caller's device is restored on return.
@@ -43,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PW_ABI_VERSION 2
+#define PW_ABI_VERSION 3
 
 /* error codes */
 #define PW_OK 0
@@ -209,6 +212,11 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       pw_engine_tune_render kept (0 before the first call) */
 #define PW_OPT_STEP_WIDE_GROUPS 12   /* sets with 17..32 movables per puzzle (N_pad 32): 0 (default) 16 lanes per environment,
                                       two movables per lane (4 environments per wavefront); 1: 32 lanes, one movable each */
+#define PW_OPT_PAGE_LOAD_ALL 13      /* ppc-3 page kernel: 1 = every page loads its static-image chunks, also the all-zero pages of
+                                      the frame padding (a more even write front; a candidate of pw_engine_tune_render) */
+#define PW_OPT_OBS_CHUNK_MB 14       /* pw_obs_alloc: MiB per physical chunk (0 = the device's allocation granularity, 2 MiB) */
+#define PW_OPT_OBS_ACCEPT_GBS 15     /* pw_obs_alloc_tuned: a candidate on which the tuned render reaches this many GB/s is
+                                      kept without looking further (default 6880 = 0.86 of the 8 TB/s peak) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order
@@ -225,6 +233,27 @@ int pw_engine_profile_read(PwEngine* e, float* ms, int32_t cap);
  * observation buffer, e.g. right after allocating it. */
 int pw_engine_tune_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, void* obs,
                           int64_t env_stride_bytes, int32_t batch, void* stream);
+
+/* Observation buffers owned by the library.  What the HBM-write-bound render kernel reaches on a buffer follows the
+ * buffer's physical backing (two classes, 7-10 % apart, per allocation), so the library can
+ * allocate the buffer itself: one reserved address range backed by physical chunks created and mapped with the HIP
+ * virtual-memory API (hipMemCreate / hipMemAddressReserve / hipMemMap), batch * pw_engine_obs_stride(e) bytes,
+ * zero-filled, env e at obs + e * pw_engine_obs_stride(e).  The page records of `batch` environments are allocated
+ * with it, so that no later render call allocates.
+ *   pw_obs_alloc        one buffer.
+ *   pw_obs_alloc_tuned  allocates up to max_candidates buffers (all alive at once, so that each lands on other physical
+ *                       memory), runs pw_engine_tune_render on each, keeps the first that is of the fast class
+ *                       (PW_OPT_OBS_ACCEPT_GBS, or 6 % faster than the slowest seen) or else the fastest, and RELEASES
+ *                       THE OTHERS TO THE DEVICE.  The kept buffer holds the observations of (puzzle_id, pos), the engine
+ *                       its tuned launch configuration; returns the tuner's index (>= 0).  candidate_ms (host float
+ *                       [max_candidates], may be NULL) receives every candidate's tuned time, *tried how many were made.
+ *   pw_obs_free         unmaps the buffer and releases its memory to the device (synchronises the device first).
+ *                       pw_engine_destroy frees what is left.  The address range of a freed buffer stays reserved
+ *                       until the process ends (an address range costs no memory). */
+int pw_obs_alloc(PwEngine* e, int32_t batch, void** obs);
+int pw_obs_alloc_tuned(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, int32_t batch, int32_t max_candidates,
+                       void** obs, float* candidate_ms, int32_t* tried, void* stream);
+int pw_obs_free(PwEngine* e, void* obs);
 
 /* Number of out-of-range actions (not in 0..3) the step kernels of this engine have seen since the
  * last call; reads and clears the counter, synchronises `stream`.  An asynchronous caller that never

@@ -19,6 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PUSHWORLD_AMD_LIB") or os.path.join(_HERE, "lib", "libpushworld_amd.so")
 
+ABI_VERSION = 3
 PW_OK = 0
 PW_EINVAL, PW_EPARSE, PW_EGOAL, PW_ELIMIT, PW_EDEVICE, PW_ENOMEM, PW_EELEMENT = -1, -2, -3, -4, -5, -6, -7
 ORDER_PYTHON, ORDER_CPP = 0, 1
@@ -141,6 +142,10 @@ SIGNATURES = {
     "pw_engine_tune_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_engine_bad_actions": (c_int64, [c_void_p, c_void_p]),
     "pw_validate_state": (c_int64, [c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
+    "pw_obs_alloc": (c_int, [c_void_p, c_int32, POINTER(c_void_p)]),
+    "pw_obs_alloc_tuned": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, POINTER(c_void_p),
+                                   POINTER(ctypes.c_float), POINTER(c_int32), c_void_p]),
+    "pw_obs_free": (c_int, [c_void_p, c_void_p]),
 }
 
 # pw_engine_set_option keys (include/pushworld_amd.h)
@@ -157,6 +162,9 @@ OPTIONS = {
     "step_lds_tables": 10,
     "tuned_ns": 11,          # read-only
     "step_wide_groups": 12,  # N_pad 32: 0 two movables per lane (16-lane groups), 1 32-lane groups
+    "page_load_all": 13,     # ppc-3 page kernel: every page loads its static chunks
+    "obs_chunk_mb": 14,      # pw_obs_alloc: MiB per physical chunk (0 = allocation granularity)
+    "obs_accept_gbs": 15,    # pw_obs_alloc_tuned: rate at which a candidate buffer is kept right away
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1}
 
@@ -172,7 +180,7 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pw_abi_version() != 2:
+    if lib.pw_abi_version() != ABI_VERSION:
         raise ImportError("libpushworld_amd.so ABI version mismatch; rebuild it")
     return lib
 
@@ -359,6 +367,77 @@ def _ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+class _DLDevice(ctypes.Structure):
+    _fields_ = [("device_type", c_int), ("device_id", c_int)]
+
+
+class _DLDataType(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_uint8), ("bits", ctypes.c_uint8), ("lanes", ctypes.c_uint16)]
+
+
+class _DLTensor(ctypes.Structure):
+    _fields_ = [("data", c_void_p), ("device", _DLDevice), ("ndim", c_int), ("dtype", _DLDataType),
+                ("shape", POINTER(c_int64)), ("strides", POINTER(c_int64)), ("byte_offset", ctypes.c_uint64)]
+
+
+class _DLManagedTensor(ctypes.Structure):
+    pass
+
+
+_DL_DELETER = ctypes.CFUNCTYPE(None, POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", c_void_p), ("deleter", _DL_DELETER)]
+_dl_live = {}  # address of a DLManagedTensor -> (struct, shape array, holder): alive until torch calls the deleter
+
+
+@_DL_DELETER
+def _dl_deleter(mt):
+    _dl_live.pop(ctypes.addressof(mt.contents), None)  # drops the holder: its __del__ frees the buffer
+
+
+def _dlpack_tensor(holder, device_index: int, esz: int):
+    """A torch tensor over ``holder.ptr`` through a DLPack capsule (kDLROCM): no pointer-attribute query, torch calls
+    the deleter when the last tensor over the memory has gone."""
+    shape = (c_int64 * len(holder.shape))(*holder.shape)
+    mt = _DLManagedTensor()
+    mt.dl_tensor.data = holder.ptr
+    mt.dl_tensor.device = _DLDevice(10, device_index)  # kDLROCM
+    mt.dl_tensor.ndim = len(holder.shape)
+    mt.dl_tensor.dtype = _DLDataType(1 if esz == 1 else 2, 8 * esz, 1)  # kDLUInt / kDLFloat
+    mt.dl_tensor.shape = shape
+    mt.dl_tensor.strides = None
+    mt.dl_tensor.byte_offset = 0
+    mt.manager_ctx = None
+    mt.deleter = _dl_deleter
+    key = ctypes.addressof(mt)
+    _dl_live[key] = (mt, shape, holder)
+    new_capsule = ctypes.pythonapi.PyCapsule_New
+    new_capsule.restype = ctypes.py_object
+    new_capsule.argtypes = [c_void_p, c_char_p, c_void_p]
+    try:
+        return torch.from_dlpack(new_capsule(key, b"dltensor", None))
+    except Exception:
+        _dl_live.pop(key, None)
+        raise
+
+
+class _OwnedObs:
+    """Keeps a ``pw_obs_alloc`` buffer alive for the tensors over it (``__cuda_array_interface__``: torch holds a
+    reference to this object for as long as any tensor shares the memory) and frees it afterwards."""
+
+    def __init__(self, engine, ptr, shape, typestr):
+        self.engine = engine  # the engine must outlive its buffers
+        self.ptr = ptr
+        self.shape = tuple(shape)
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 3,
+                                         "strides": None}
+
+    def __del__(self):
+        eng, ptr = getattr(self, "engine", None), getattr(self, "ptr", None)
+        if eng is not None and ptr and getattr(eng, "handle", None) and lib is not None:
+            lib.pw_obs_free(eng.handle, c_void_p(ptr))
+        self.ptr = None
+
+
 class Engine:
     """Owner of a ``PwEngine*``.  Methods take torch tensors resident on the set's device and
     enqueue kernels on ``torch.cuda.current_stream()``."""
@@ -462,6 +541,40 @@ class Engine:
         h, w, c = self.obs_shape
         view = storage.as_strided((batch, h, w, c), (self.obs_stride // esz, w * c, c, 1))
         return storage, view
+
+    def _wrap_owned(self, ptr: int, batch: int):
+        """(storage, view) tensors over a library-owned buffer; the memory goes back to the DEVICE (``pw_obs_free``)
+        when the last tensor over it has gone."""
+        esz = 1 if self.obs_dtype == torch.uint8 else 4
+        holder = _OwnedObs(self, ptr, (batch, self.obs_stride // esz), "|u1" if esz == 1 else "<f4")
+        try:
+            storage = _dlpack_tensor(holder, self.device.index, esz)
+        except Exception:  # noqa: BLE001 -- second route into torch: the CUDA array interface
+            holder.owned_by_dlpack = False
+            storage = torch.as_tensor(holder, device=self.device)
+        if storage.data_ptr() != ptr or storage.dtype != self.obs_dtype or storage.device != self.device:
+            raise RuntimeError("torch did not adopt the library-owned observation buffer in place")
+        h, w, c = self.obs_shape
+        view = storage.as_strided((batch, h, w, c), (self.obs_stride // esz, w * c, c, 1))
+        return storage, view
+
+    def alloc_obs_owned(self, batch: int):
+        """``pw_obs_alloc``: like ``alloc_obs`` but the buffer is owned by the library (HIP virtual-memory API), not
+        by torch's caching allocator."""
+        p = c_void_p()
+        check(lib.pw_obs_alloc(self.handle, batch, ctypes.byref(p)))
+        return self._wrap_owned(p.value, batch)
+
+    def alloc_obs_tuned(self, puzzle_id, pos, max_candidates: int):
+        """``pw_obs_alloc_tuned``: returns (storage, view, tuned index, [ms of every candidate tried]); the buffer
+        holds the observations of ``pos``, the engine the tuned launch configuration."""
+        p, tried = c_void_p(), c_int32(0)
+        k = max(1, int(max_candidates))
+        ms = (ctypes.c_float * k)()
+        idx = check(lib.pw_obs_alloc_tuned(self.handle, _ptr(puzzle_id), _ptr(pos), pos.shape[0], k, ctypes.byref(p), ms,
+                                           ctypes.byref(tried), self._stream()))
+        storage, view = self._wrap_owned(p.value, pos.shape[0])
+        return storage, view, idx, [float(ms[i]) for i in range(tried.value)]
 
     # kernels ---------------------------------------------------------------------------
     def reset(self, puzzle_id, pos, steps, terminated=None, truncated=None, mask=None):

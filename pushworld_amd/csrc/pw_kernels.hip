@@ -36,6 +36,16 @@
 #define PW_RENDER_THREADS 256  // workgroup size of the render kernels (one environment each)
 #endif
 
+// An observation buffer owned by the library (pw_obs_alloc): one reserved address range backed by physical chunks
+// created and mapped with the HIP virtual-memory API.  Unmapped and released to the DEVICE by pw_obs_free /
+// pw_engine_destroy (not to a caching allocator); the address range itself is never handed back (see pw_obs_free).
+struct PwObsBuf {
+  void* ptr;
+  size_t bytes;   // mapped bytes (a multiple of the chunk size)
+  size_t chunk;
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+
 struct PwEngine {
   const PwPuzzleSet* set;
   PwEngineConfig cfg;
@@ -68,10 +78,14 @@ struct PwEngine {
   // launch configuration of the page-ordered render kernel (CopyArgs::order / run_log2, dynamic LDS as an
   // occupancy cap); defaults are the robust optimum, pw_engine_tune_render measures the caller's buffer
   int page_order, page_run_log2, page_lds_pad_kb;
+  int page_load_all;       // PW_OPT_PAGE_LOAD_ALL: the ppc-3 page kernel loads the static chunks of every page (kLoadAll)
   int64_t tuned_ns;        // nanoseconds per launch of the configuration pw_engine_tune_render kept (0: never tuned)
   bool tuning;             // inside pw_engine_tune_render: trial launches use the kTag = 1 symbol of the page kernel
-  void* d_rec;             // page records (PageRec [rec_cap]), grown on demand
-  int64_t rec_cap;
+  void* d_rec;             // page records (PageRec [rec_cap]): allocated with the first observation buffer / render
+  int64_t rec_cap;         //   call of a batch size, grown (never shrunk) when a larger batch arrives
+  std::vector<PwObsBuf> obs_bufs;  // pw_obs_alloc
+  int obs_chunk_mb;        // PW_OPT_OBS_CHUNK_MB: physical chunk size of pw_obs_alloc (0 = the allocation granularity)
+  int obs_accept_gbs;      // PW_OPT_OBS_ACCEPT_GBS: pw_obs_alloc_tuned keeps the first candidate that reaches this
   // PW_OPT_PROFILE_RENDER: HIP event pairs around the dominant (render) launch, on the launch stream
   std::vector<hipEvent_t> prof_events;  // 2 per slot
   int prof_used;

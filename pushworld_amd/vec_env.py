@@ -47,16 +47,16 @@ class VecPushWorld:
             start of the ``step`` that resets a finished environment.
         seed: seed of the counter-based draw: puzzle = f(seed, environment index, episode number).
         tune: auto-tune the launch configuration of the page-ordered render kernel on this environment's own
-            observation buffer at the first ``reset`` (``pw_engine_tune_render``, a few dozen extra render launches
-            once).  Default: on for observation buffers of 256 MB and more, where the choice is worth 5-15 %.
-        tune_allocations: with ``tune`` (default: up to 8, within a quarter of the free device memory): try up to this
-            many allocations of the observation buffer and keep the one
-            the tuned render kernel is fastest on (the others are freed); stops at the first one that is 6 % faster
-            than the slowest seen.  Buffers of identical size and alignment differ by up to 10 % in what the kernel
-            reaches on them -- it follows their physical backing, about one allocation in five is of the fast class
-             -- so a long training job can afford k allocations + k tuner runs (~0.1 s each at
-            3.8 GB) once.  ``self.obs`` is bound to the chosen buffer at the first ``reset``: take the observation
-            tensor from the return values of ``reset`` / ``step`` (or read ``self.obs`` afterwards).
+            observation buffer (``pw_engine_tune_render``, a few dozen extra render launches in the constructor).
+            Default: on for observation buffers of 256 MB and more, where the choice is worth 5-15 %.
+        tune_allocations: with ``tune``: the observation buffer is allocated BY THE LIBRARY (``pw_obs_alloc_tuned``:
+            physical chunks mapped with the HIP virtual-memory API) from up to this many candidate allocations
+            (default: up to 4, within a quarter of the free device memory).  What the HBM-write-bound render reaches
+            on a buffer follows the buffer's physical backing -- two classes, 7-10 % apart, per allocation
+             -- so the library tunes on one candidate after the other, all alive at once,
+            keeps the first of the fast class and releases the others to the DEVICE (nothing stays behind in
+            torch's caching allocator).  ``self.obs`` is bound once, in the constructor.  0: a plain torch buffer,
+            tuned in place.
         engine_options: ``pw_engine_set_option`` settings (``_capi.OPTIONS``), e.g. ``{"step_kernel": "lane"}`` --
             kernel selection for tests and A/B runs; results never depend on them.
     """
@@ -105,23 +105,31 @@ class VecPushWorld:
         self.pos, self.steps = st["pos"], st["steps"]
         self.reward, self.dgoals = st["reward"], st["dgoals"]
         self.terminated, self.truncated = st["terminated"], st["truncated"]
-        if observation is not None:
-            self._obs_storage, self.obs = self.engine.alloc_obs(self.num_envs)
-        else:
-            self._obs_storage, self.obs = None, None
-        self._has_reset = False
-        if tune is None:
-            tune = self.obs is not None and self.num_envs * self.engine.obs_stride >= (256 << 20)
-        self._tune_pending = bool(tune) and self.obs is not None
-        if tune_allocations is None:  # as many as fit into a quarter of the free device memory, at most 8
-            tune_allocations = 1
-            if self._tune_pending:
-                free, _ = torch.cuda.mem_get_info(self.device)
-                tune_allocations = min(8, max(1, int(free // 4 // (self.num_envs * self.engine.obs_stride))))
-        self._tune_allocations = max(1, int(tune_allocations))
-        self.tuned_config = None  # index returned by pw_engine_tune_render, once it ran
+        self.tuned_config = None  # index returned by the tuner, once it ran
         self.tuned_ms = None      # milliseconds per render launch it measured for that configuration
         self.tuned_candidates_ms = []  # the same for every candidate allocation it tried (tune_allocations)
+        self._has_reset = False
+        self._obs_storage, self.obs = None, None
+        if observation is not None:
+            nbytes = self.num_envs * self.engine.obs_stride
+            if tune is None:
+                tune = nbytes >= (256 << 20)
+            if tune and tune_allocations is None:  # as many as fit into a quarter of the free device memory, at most 4
+                free, _ = torch.cuda.mem_get_info(self.device)
+                tune_allocations = min(4, max(1, int(free // 4 // nbytes)))
+            if tune and tune_allocations:
+                # library-owned buffer: candidates are tuned on the initial states (reset() draws them again)
+                self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, None)
+                self._obs_storage, self.obs, self.tuned_config, self.tuned_candidates_ms = \
+                    self.engine.alloc_obs_tuned(self.puzzle_id, self.pos, int(tune_allocations))
+                self.tuned_ms = self.engine.get_option("tuned_ns") * 1e-6
+            else:
+                self._obs_storage, self.obs = self.engine.alloc_obs(self.num_envs)
+                if tune:
+                    self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, None)
+                    self.tuned_config = self.engine.tune_render(self.puzzle_id, self.pos, self._obs_storage)
+                    self.tuned_ms = self.engine.get_option("tuned_ns") * 1e-6
+                    self.tuned_candidates_ms = [self.tuned_ms]
 
         self.seed = int(seed)
         self.resample = resample is not False and resample is not None
@@ -156,46 +164,9 @@ class VecPushWorld:
         self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, mask)
         self._has_reset = True
         if self.obs is not None:
-            if self._tune_pending:  # renders, too
-                self._tune()
-                self._tune_pending = False
-            else:
-                self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+            self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
             self._obs_current = True
         return self.obs
-
-    def _tune(self) -> None:
-        """``pw_engine_tune_render`` on this environment's observation buffer -- on ``tune_allocations`` candidate
-        buffers, keeping the one the render kernel is fastest on."""
-        eng = self.engine
-        keys = ("page_order", "page_run_log2", "page_lds_pad_kb")
-        best = None
-        candidates = []  # all kept alive until the choice is made: every new one lands on other physical memory
-        self.tuned_candidates_ms = []  # best launch time on every candidate buffer, in allocation order
-        for k in range(self._tune_allocations):
-            if k == 0:
-                storage, view = self._obs_storage, self.obs
-            else:
-                try:
-                    storage, view = eng.alloc_obs(self.num_envs)
-                except RuntimeError:  # out of memory: choose among the candidates there are
-                    break
-            candidates.append((storage, view))
-            idx = eng.tune_render(self.puzzle_id, self.pos, storage)
-            ns = eng.get_option("tuned_ns")
-            self.tuned_candidates_ms.append(ns * 1e-6)
-            if best is None or ns < best[0]:
-                best = (ns, idx, tuple(eng.get_option(k_) for k_ in keys), storage, view)
-            # a buffer of the fast class shows as >= 6 % under the slowest one seen: no need to look further
-            if best[0] <= 0.94e6 * max(self.tuned_candidates_ms):
-                break
-        ns, idx, cfg, storage, view = best
-        for k, v in zip(keys, cfg):
-            eng.set_option(k, v)
-        if storage is not self._obs_storage:  # the losers go back to the allocator; the winner holds the render
-            self._obs_storage, self.obs = storage, view
-        del candidates
-        self.tuned_config, self.tuned_ms = idx, ns * 1e-6
 
     def step(self, actions: torch.Tensor):
         """gym_env.py:188-226 for every environment.
