@@ -180,6 +180,16 @@ int pw_grid_to_text(const uint8_t* grid, int32_t width, int32_t height, int32_t 
 /* packed header array (host copy), for tests */
 int pw_puzzleset_headers(const PwPuzzleSet* s, const void** data, size_t* bytes);
 
+/* Overlap tables (PW_OPT_STEP_TABLES) of a set as the engine builds them, for tests / inspection (host only, works on
+ * device < 0 sets).  The compressed form of the reference's collision tables (puzzle.py:259-311, :522-593):
+ *   pair table (i, j), R rows:  bit (rx + w_i - 1) of row (ry + h_i - 1) = movable i at (rx, ry) relative to movable j
+ *                               overlaps it;  "i pushes j with displacement d" = overlap at r + d and not at r
+ *   wall table j, H + 2 rows:   bit (x + 1) of row (y + 1) = movable j at (x, y) overlaps a wall (j = 0: or agent wall)
+ * dir: uint32 [count][4] = {pair_off, wall_off, R | (H + 2) << 16, 0} in 8-byte words (pair_off 0 = no tables; pair
+ * table (i, j) at pair_off + (i * N + j) * R, wall table j at wall_off + j * (H + 2)).  Returns the number of words
+ * (writes them when cap_words suffices). */
+int64_t pw_puzzleset_overlap_tables(const PwPuzzleSet* s, int mode, uint64_t* words, int64_t cap_words, uint32_t* dir);
+
 /* ---------------------------------------------------------------------- engine */
 int pw_engine_create(const PwPuzzleSet* s, const PwEngineConfig* cfg, PwEngine** out);
 void pw_engine_destroy(PwEngine* e);
@@ -217,6 +227,13 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_OBS_CHUNK_MB 14       /* pw_obs_alloc: MiB per physical chunk (0 = the device's allocation granularity, 2 MiB) */
 #define PW_OPT_OBS_ACCEPT_GBS 15     /* pw_obs_alloc_tuned: a candidate on which the tuned render reaches this many GB/s is
                                       kept without looking further (default 6880 = 0.86 of the 8 TB/s peak) */
+#define PW_OPT_STEP_TABLES 16         /* overlap tables for the lane-group step / expansion / search kernels (the reference's
+                                      collision tables, puzzle.py:259-311, with the four actions sharing one table; one or two
+                                      8-byte loads instead of a loop over object rows): 0 (default) for puzzles with a movable
+                                      beyond 8 x 8 cells, 1 for every puzzle, 2 none.  Setting it rebuilds the tables
+                                      (synchronises the device) */
+#define PW_OPT_STEP_TABLE_BYTES 17   /* read-only: bytes of overlap tables in HBM */
+#define PW_OPT_STEP_TABLE_PUZZLES 18 /* read-only: puzzles of the set that have overlap tables */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

@@ -142,6 +142,7 @@ SIGNATURES = {
     "pw_engine_tune_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_engine_bad_actions": (c_int64, [c_void_p, c_void_p]),
     "pw_validate_state": (c_int64, [c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
+    "pw_puzzleset_overlap_tables": (c_int64, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "pw_obs_alloc": (c_int, [c_void_p, c_int32, POINTER(c_void_p)]),
     "pw_obs_alloc_tuned": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, POINTER(c_void_p),
                                    POINTER(ctypes.c_float), POINTER(c_int32), c_void_p]),
@@ -165,8 +166,11 @@ OPTIONS = {
     "page_load_all": 13,     # ppc-3 page kernel: every page loads its static chunks
     "obs_chunk_mb": 14,      # pw_obs_alloc: MiB per physical chunk (0 = allocation granularity)
     "obs_accept_gbs": 15,    # pw_obs_alloc_tuned: rate at which a candidate buffer is kept right away
+    "step_tables": 16,       # overlap tables: 0 / "big" puzzles with movables beyond 8 x 8, 1 / "all", 2 / "none"
+    "step_table_bytes": 17,    # read-only
+    "step_table_puzzles": 18,  # read-only
 }
-_OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1}
+_OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 0, "all": 1, "none": 2}
 
 
 def _load():
@@ -349,6 +353,16 @@ class PuzzleSet:
         p, n = c_void_p(), c_size_t()
         check(lib.pw_puzzleset_blob(self.handle, ctypes.byref(p), ctypes.byref(n)))
         return ctypes.string_at(p.value, n.value)
+
+    def overlap_tables(self, mode: int = 0):
+        """``pw_puzzleset_overlap_tables``: (words uint64 [n], dir uint32 [count, 4]) as numpy arrays."""
+        import numpy as np
+
+        n = check(lib.pw_puzzleset_overlap_tables(self.handle, mode, None, 0, None))
+        words = np.zeros((n,), np.uint64)
+        d = np.zeros((self.count, 4), np.uint32)
+        check(lib.pw_puzzleset_overlap_tables(self.handle, mode, c_void_p(words.ctypes.data), n, c_void_p(d.ctypes.data)))
+        return words, d
 
     def headers(self) -> bytes:
         """The packed ``PwPuzzleHeader`` array (320 bytes per puzzle, csrc/pw_format.h)."""

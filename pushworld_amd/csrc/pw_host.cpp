@@ -548,6 +548,8 @@ static const char* pw_validate_packed_puzzle(const PwPuzzleHeader& h, const uint
       !inside(h.off_mcells, 4ull * std::max<uint32_t>(h.n_mcells, 1u), 4) || h.n_mcells > 64u * 64u ||
       !inside(h.off_small, 8ull * h.N, 8))
     return "table offsets out of range";
+  // the LDS-staged step kernel copies (off_static - off_shapes) / 8 shape rows: the packer's section order
+  if (h.off_static < h.off_shapes || h.off_static - h.off_shapes < 8ull * shape_rows) return "table sections out of order";
   const uint64_t width_mask = h.W >= 64 ? ~0ull : ((1ull << h.W) - 1ull);
   const uint64_t* wall = reinterpret_cast<const uint64_t*>(blob + h.base + h.off_wall);
   const uint64_t* awall = reinterpret_cast<const uint64_t*>(blob + h.base + h.off_awall);
@@ -602,13 +604,15 @@ int pw_puzzleset_save(const PwPuzzleSet* s, const char* path) try {
 
 int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) try {
   if (!path || !out) return pw_fail(PW_EINVAL, "null argument");
-  FILE* f = std::fopen(path, "rb");
+  // owners: whatever throws below (the host vectors of a multi-GB set), the file and the set are released
+  struct FileOwner {
+    FILE* f;
+    ~FileOwner() { if (f) std::fclose(f); }
+  } file{std::fopen(path, "rb")};
+  FILE* f = file.f;
   if (!f) return pw_fail(PW_EINVAL, std::string("cannot open: ") + path);
   PwSetFileHeader fh;
-  auto bad = [&](const char* why) {
-    std::fclose(f);
-    return pw_fail(PW_EPARSE, std::string(path) + ": " + why);
-  };
+  auto bad = [&](const char* why) { return pw_fail(PW_EPARSE, std::string(path) + ": " + why); };
   if (std::fread(&fh, sizeof(fh), 1, f) != 1) return bad("truncated file header");
   if (std::memcmp(fh.magic, "PWSET\0\0\0", 8) != 0) return bad("not a packed puzzle set");
   if (fh.version != PW_SETFILE_VERSION || fh.header_bytes != sizeof(PwPuzzleHeader)) return bad("unsupported format version");
@@ -622,11 +626,12 @@ int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) try {
     if (size < 0 || static_cast<uint64_t>(size) != want) return bad(static_cast<uint64_t>(size) < want ? "truncated file" : "trailing bytes");
     if (std::fseek(f, static_cast<long>(sizeof(fh)), SEEK_SET) != 0) return bad("cannot seek");
   }
-  PwPuzzleSet* s = new (std::nothrow) PwPuzzleSet();
-  if (!s) {
-    std::fclose(f);
-    return pw_fail(PW_ENOMEM, "out of memory");
-  }
+  struct SetOwner {
+    PwPuzzleSet* s;
+    ~SetOwner() { delete s; }
+  } owner{new (std::nothrow) PwPuzzleSet()};
+  PwPuzzleSet* s = owner.s;
+  if (!s) return pw_fail(PW_ENOMEM, "out of memory");
   s->device = device;
   s->count = fh.count;
   s->max_w = fh.max_w;
@@ -637,19 +642,15 @@ int pw_puzzleset_load(const char* path, int device, PwPuzzleSet** out) try {
   const size_t hb = static_cast<size_t>(fh.count) * sizeof(PwPuzzleHeader);
   const bool ok = std::fread(s->headers.data(), hb, 1, f) == 1 &&
                   (s->blob.empty() || std::fread(s->blob.data(), s->blob.size(), 1, f) == 1);
-  if (!ok || fnv1a64(s->blob.data(), s->blob.size(), fnv1a64(s->headers.data(), hb, 0xCBF29CE484222325ull)) != fh.checksum) {
-    delete s;
+  if (!ok || fnv1a64(s->blob.data(), s->blob.size(), fnv1a64(s->headers.data(), hb, 0xCBF29CE484222325ull)) != fh.checksum)
     return bad(ok ? "checksum mismatch" : "truncated file");
-  }
-  std::fclose(f);
   // The kernels index with every field below unchecked (LDS writes included), and FNV-1a is no protection
   // against a crafted file: validate the full extent of every section and every index stored in them.
   for (const PwPuzzleHeader& h : s->headers) {
-    if (const char* why = pw_validate_packed_puzzle(h, s->blob.data(), s->blob.size())) {
-      delete s;
+    if (const char* why = pw_validate_packed_puzzle(h, s->blob.data(), s->blob.size()))
       return pw_fail(PW_EPARSE, std::string(path) + ": " + why);
-    }
   }
+  owner.s = nullptr;  // upload_set destroys the set itself when it fails
   if (int rc = upload_set(s)) return rc;
   *out = s;
   return PW_OK;

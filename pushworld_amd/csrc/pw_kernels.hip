@@ -36,6 +36,23 @@
 #define PW_RENDER_THREADS 256  // workgroup size of the render kernels (one environment each)
 #endif
 
+// Overlap tables of one puzzle (engine-built, csrc/pw_engine.inc build_overlap_tables): what is left of the reference's
+// collision tables (puzzle.py:259-311) once the four actions share one table.
+//   pair table (i, j), R rows of uint64:   bit (rx + w_i - 1) of row (ry + h_i - 1) = movable i placed at (rx, ry)
+//                                          relative to movable j overlaps it          ("i pushes j" = overlap after the
+//                                          move and not before, puzzle.py:567-593)
+//   wall table j, Hs = H + 2 rows:         bit (x + 1) of row (y + 1) = movable j at (x, y) overlaps a wall cell (the
+//                                          agent: wall or agent wall)                 (puzzle.py:522-564)
+// One or two 8-byte loads replace the row loops of lane_pushes / lane_blocked for objects that do not fit the 8 x 8
+// boards.  16 bytes per puzzle, indexed by puzzle id (same dependency level as the puzzle header).
+struct PwOvlDir {
+  uint32_t pair_off;  // offset of pair table (0, 0) in 8-byte units; 0 = this puzzle has no tables
+  uint32_t wall_off;  // offset of wall table 0
+  uint16_t R;         // rows per pair table: max h_i + max h_j - 1
+  uint16_t Hs;        // rows per wall table: H + 2
+  uint32_t reserved;
+};
+
 // An observation buffer owned by the library (pw_obs_alloc): one reserved address range backed by physical chunks
 // created and mapped with the HIP virtual-memory API.  Unmapped and released to the DEVICE by pw_obs_free /
 // pw_engine_destroy (not to a caching allocator); the address range itself is never handed back (see pw_obs_free).
@@ -75,6 +92,12 @@ struct PwEngine {
   int step_lds_tables;     // PW_OPT_STEP_LDS_TABLES: the group step kernel stages the puzzle's row tables in LDS:
                            // 0 automatic (launches of >= 4 steps), 1 always, 2 never
   bool lds_tables_fit;     // every puzzle of the set has <= 128 shape rows
+  int step_tables;         // PW_OPT_STEP_TABLES: which puzzles get overlap tables: 0 those with a movable beyond 8 x 8,
+                           // 1 every puzzle, 2 none
+  uint64_t* d_ovl;         // overlap tables of all puzzles that have them (word 0 unused)
+  PwOvlDir* d_ovl_dir;     // [set size]
+  int64_t ovl_bytes;
+  int ovl_puzzles;         // puzzles with tables
   // launch configuration of the page-ordered render kernel (CopyArgs::order / run_log2, dynamic LDS as an
   // occupancy cap); defaults are the robust optimum, pw_engine_tune_render measures the caller's buffer
   int page_order, page_run_log2, page_lds_pad_kb;

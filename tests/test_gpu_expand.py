@@ -48,15 +48,25 @@ def bfs(puzzle, max_states):
     "bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp", "bench:level4/Four Pistons.pwp",
     "bench:level1/Pulling.pwp", "bench:level3/Armor.pwp",
     "bench:level2/Clean Sweep.pwp",  # 19 movables: the 32-lane instantiation
+    # movables beyond 8 x 8 cells: overlap tables by default (PW_OPT_STEP_TABLES), the row loops with "none"
+    "bench:level4/Mind The Gap.pwp", "bench:level4/Mind The Gap.pwp|none", "bench:level2/Bubbles.pwp",
+    "bench:level3/Rocky Shore.pwp", "bench:level3/Rocky Shore.pwp|none", "bench:level3/Moving Mountains.pwp",
+    # ... and tables for puzzles of small movables
+    "bench:level1/2 Obstacle.pwp|all", "bench:level4/Four Pistons.pwp|all", "bench:level2/Clean Sweep.pwp|all",
+    "cpptest:necessary_transitive_pushing3.pwp|all",
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle
     from pushworld_amd.puzzle import PushWorldPuzzle
 
+    key, _, tables = key.partition("|")
     if key not in golden.meta:
         pytest.skip("puzzle not in the fixture set")
     text = golden.text(key)
     pz = PushWorldPuzzle(text=text, order="cpp")
+    if tables:
+        pz._engine().set_option("step_tables", tables)
+        assert (pz._engine().get_option("step_table_puzzles") == 1) == (tables == "all")
     oz = c_oracle.COraclePuzzle(text, order="cpp")
     assert tuple(pz.initial_state) == tuple(oz.initial_state)
     order, succ, moved, goal, n = bfs(pz, 6000)

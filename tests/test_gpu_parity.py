@@ -43,7 +43,12 @@ def _groups(golden):
 def _step_options(kernel):
     """engine options of a step-kernel flavour: "group" (default: row tables read from global memory for single
     steps; pools with more than 16 movables per puzzle: two per lane), "group-lds" (row tables staged in LDS, the
-    default of multi-step rollouts), "group-wide" (32-lane groups), "lane", "wave"."""
+    default of multi-step rollouts), "group-wide" (32-lane groups), "lane", "wave"; "group-tables" / "group-notables":
+    overlap tables (PW_OPT_STEP_TABLES) for every puzzle / for none (default: for puzzles with movables beyond 8 x 8)."""
+    if kernel == "group-tables":
+        return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "all"}
+    if kernel == "group-notables":
+        return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "none"}
     if kernel == "group-lds":
         return {"step_kernel": "group", "step_lds_tables": 1}
     if kernel == "group-wide":  # N_pad 32 pools: 32 lanes per environment instead of two movables per lane
@@ -54,6 +59,8 @@ def _step_options(kernel):
 @pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
                                           ("bench", "group-lds"), ("tests", "group-lds"), ("l0", "group-lds"),
                                           ("bench", "group-wide"),
+                                          ("bench", "group-tables"), ("tests", "group-tables"), ("l0", "group-tables"),
+                                          ("bench", "group-notables"), ("tests", "group-notables"),
                                           ("bench", "lane"), ("tests", "lane"), ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
@@ -112,7 +119,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "lane", "wave"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-tables", "group-notables", "lane", "wave"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""

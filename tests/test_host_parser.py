@@ -324,3 +324,83 @@ def test_parser_fuzz_vectors_from_the_reference():
         # the reference property returns AW u W (SURVEY trap T2); the C ABI exposes the raw "aw" cells
         assert sorted(map(list, o.agent_wall_cells)) == want["agent_walls"], i
     assert n_ok > 100
+
+
+def _sets_from_overlap_tables(words, d, parsed):
+    """The reference's collision sets (puzzle.py:259-311) read back out of the engine's overlap tables."""
+    W, H, n = parsed.width, parsed.height, parsed.num_movables
+    pair_off, wall_off, R, Hs = int(d[0]), int(d[1]), int(d[2]) & 0xffff, int(d[2]) >> 16
+    assert pair_off > 0 and Hs == H + 2
+    dims = []
+    for cells in parsed.object_cells:
+        dims.append((max(c[0] for c in cells) + 1, max(c[1] for c in cells) + 1))
+
+    def bits(rows):  # uint64 rows -> bool [len(rows) + 2, 66], one cell of zero margin all around
+        a = np.zeros((len(rows) + 2, 66), bool)
+        a[1:-1, 1:65] = ((rows[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+        return a
+
+    disp = [(-1, 0), (1, 0), (0, -1), (0, 1)]
+    static = [[set() for _ in range(n)] for _ in range(4)]
+    dynamic = [[[set() for _ in range(n)] for _ in range(n)] for _ in range(4)]
+    for i in range(n):
+        w, h = dims[i]
+        t = bits(words[wall_off + i * Hs: wall_off + (i + 1) * Hs])  # t[y + 2, x + 2] = object i at (x, y) overlaps
+        for a, (dx, dy) in enumerate(disp):
+            now = t[2:2 + H - h + 1, 2:2 + W - w + 1]
+            nxt = t[2 + dy:2 + dy + H - h + 1, 2 + dx:2 + dx + W - w + 1]
+            ys, xs = np.nonzero(nxt & ~now)
+            static[a][i] = set(zip(xs.tolist(), ys.tolist()))
+        for j in range(1, n):
+            o = bits(words[pair_off + (i * n + j) * R: pair_off + (i * n + j + 1) * R])  # o[ry + h + 1 - 1, rx + w + 1 - 1]
+            for a, (dx, dy) in enumerate(disp):
+                now = o[1:-1, 1:-1]
+                nxt = np.roll(np.roll(o, -dy, axis=0), -dx, axis=1)[1:-1, 1:-1]  # nxt[r] = o[r + d]
+                ys, xs = np.nonzero(nxt & ~now)
+                dynamic[a][i][j] = set(zip((xs - (w - 1)).tolist(), (ys - (h - 1)).tolist()))
+                # offsets just outside the table (r + d is its first / last row or column)
+                for ry in range(-1, R + 1):
+                    for rx in range(-1, 65):
+                        if 0 <= ry < R and 0 <= rx < 64:
+                            continue
+                        yy, xx = ry + dy, rx + dx
+                        if 0 <= yy < R and 0 <= xx < 64 and o[yy + 1, xx + 1]:
+                            dynamic[a][i][j].add((rx - (w - 1), ry - (h - 1)))
+    return static, dynamic
+
+
+def test_overlap_tables_are_the_reference_collision_tables(golden):
+    """PW_OPT_STEP_TABLES: the sets read back out of the engine's overlap tables have the sizes and the
+    SHA-256 (over sorted contents) the reference's own tables have -- every benchmark puzzle with a movable beyond
+    8 x 8 cells (the ones that get tables by default) plus a sample of the others (mode 1: every puzzle)."""
+    big = []
+    for k in golden.keys:
+        if k.startswith("bench:") and any(max(c[0] for c in cells) >= 8 or max(c[1] for c in cells) >= 8
+                                           for cells in golden.meta[k]["object_cells"]):
+            big.append(k)
+    assert len(big) >= 40
+    rest = [k for k in golden.keys if k not in big]
+    keys = big + rest[::9]
+    parsed = [_capi.ParsedPuzzle(golden.text(k), _capi.ORDER_PYTHON) for k in keys]
+    pset = _capi.PuzzleSet(parsed, -1)
+    words0, dir0 = pset.overlap_tables(0)
+    assert [bool(d[0]) for d in dir0] == [k in big for k in keys]  # default: exactly the puzzles with big movables
+    assert pset.overlap_tables(2)[0].size == 1
+    words, dirs = pset.overlap_tables(1)
+    assert all(d[0] for d in dirs)
+    for k, p, d, d0 in zip(keys, parsed, dirs, dir0):
+        if d0[0]:  # same tables whichever mode built them
+            n_words = p.num_movables ** 2 * (int(d[2]) & 0xffff) + p.num_movables * (int(d[2]) >> 16)
+            assert np.array_equal(words[int(d[0]): int(d[0]) + n_words], words0[int(d0[0]): int(d0[0]) + n_words])
+        m = golden.meta[k]
+        static, dynamic = _sets_from_overlap_tables(words, d, p)
+        n = p.num_movables
+        h = hashlib.sha256()
+        for a in range(4):
+            for i in range(n):
+                assert len(static[a][i]) == m["static_sizes"][a][i], (k, a, i)
+                h.update(np.array(sorted(static[a][i]), np.int32).tobytes())
+                for j in range(n):
+                    assert len(dynamic[a][i][j]) == m["dynamic_sizes"][a][i][j], (k, a, i, j)
+                    h.update(np.array(sorted(dynamic[a][i][j]), np.int32).tobytes())
+        assert h.hexdigest() == m["tables_sha"], k
