@@ -53,6 +53,14 @@ def level1_paths():
     return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".pwp")]
 
 
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001 -- no git on the box, not a checkout
+        return None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -216,6 +224,8 @@ def spawn_ranks(args):
               f"ranks than asked (use --shared-device only to test the plumbing on one GPU)", file=sys.stderr)
         return 2
     env = dict(os.environ)
+    # the host driver of these boxes only supports dmabuf IPC: without it RCCL's cross-process buffer exchange fails with
+    # "hipIpcGetMemHandle: invalid argument" (exported by the image already; kept for environments built by hand)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["PUSHWORLD_BENCH_SPAWNED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -248,6 +258,7 @@ def main():
                     help="plumbing test on a 1-GPU box: all ranks on cuda:0, gloo for the counter reduction "
                          "(RCCL refuses two ranks on one device)")
     ap.add_argument("--fused", type=int, default=0, help="1: single fused step+render launch (engine option)")
+    ap.add_argument("--no-numa-pin", action="store_true", help="do not pin the launching thread to the GPU's NUMA node")
     ap.add_argument("--tune-allocations", type=int, default=None,
                     help="at most this many candidate allocations of the library-owned observation buffer (pw_obs_alloc_tuned "
                          "keeps the first one of the fast class); default: the product default of VecPushWorld")
@@ -286,13 +297,24 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.shared_device:
-            backend = "gloo"
-            dist.init_process_group(backend="gloo")
-        else:
-            backend = "nccl"
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        backend = "gloo" if args.shared_device else "nccl"
+        try:
+            if backend == "gloo":
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+                probe = torch.ones(1, device=torch.device("cuda", device_index))
+                dist.all_reduce(probe)  # the first collective creates the RCCL communicator: fail here, loudly
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+        except Exception as exc:  # noqa: BLE001 -- never fall back to fewer ranks or another backend
+            print(f"bench.py: rank {rank}: torch.distributed ({backend}) failed: {exc!r}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
     red_dev = None if backend == "gloo" else torch.device("cuda", device_index)
+    # the launching thread next to its GPU (NUMA); the CPU baseline later gets the original mask back
+    from pushworld_amd.sharding import pin_to_device_numa
+    numa_node, affinity_before = (None, None) if args.no_numa_pin else pin_to_device_numa(device_index)
 
     wl = build_workload(args, rank, world, device_index)
     vec = wl["vec"]
@@ -334,7 +356,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    from pushworld_amd.sharding import gather_floats, reduce_counters, reduce_max
+    from pushworld_amd.sharding import gather_floats, gather_vectors, reduce_counters, reduce_max
 
     for t in range(Wm):
         one_step(t)
@@ -375,6 +397,20 @@ def main():
     per_rank = gather_floats(own_median, device=red_dev)
     if counters["ranks"] != world:
         raise SystemExit(f"bench.py: only {counters['ranks']} of {world} ranks reported")
+    # every rank's dominant-kernel time and what its allocator found (a few floats per rank)
+    if obs_mode is not None:
+        own_ms = np.array(eng.profile_read(), dtype=np.float64)
+        assert len(own_ms) == K * M, (len(own_ms), K, M)
+        tuned_ms = float(vec.tuned_ms or 0.0)
+        own_gbs = B * eng.obs_bytes / (tuned_ms * 1e-3) / 1e9 if tuned_ms > 0 else 0.0
+        rank_row = [float(own_ms.mean()), float(np.median(own_ms)), float(own_ms.min()), tuned_ms,
+                    float(len(vec.tuned_candidates_ms)), 1.0 if own_gbs >= eng.get_option("obs_accept_gbs") else 0.0,
+                    -1.0 if numa_node is None else float(numa_node)]
+    else:
+        own_ms = np.array([a.elapsed_time(b) for a, b in step_events], dtype=np.float64)
+        rank_row = [float(own_ms.mean()), float(np.median(own_ms)), float(own_ms.min()), 0.0, 0.0, 0.0,
+                    -1.0 if numa_node is None else float(numa_node)]
+    rank_rows = gather_vectors(rank_row, device=red_dev)
     elapsed = float(np.median(win_max))
     total_steps = counters["env_steps"]  # per window, all ranks
 
@@ -383,6 +419,11 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
+    if affinity_before is not None:  # the CPU baselines below use every core this process may use
+        try:
+            os.sched_setaffinity(0, affinity_before)
+        except OSError:
+            pass
 
     n_obj = eng.np
     state_bytes = 2 * n_obj * 2 + 1 + 4 + 4 * 2 + 8 + 1 + 1 + 1  # pos r/w, action, pid, steps r/w, reward, flags
@@ -438,9 +479,9 @@ def main():
             "per_rank_median_ms_per_step": [1000.0 * w / K for w in per_rank],
         },
     }
+    out["timing"]["numa_node_per_rank"] = [None if r[6] < 0 else int(r[6]) for r in rank_rows]
     if obs_mode is not None:
-        ms = np.array(eng.profile_read(), dtype=np.float64)
-        assert len(ms) == K * M, (len(ms), K, M)
+        ms = own_ms
         render_s = float(ms.mean()) * 1e-3
         # render launch: observation write + positions and puzzle id read
         algo = B * (eng.obs_bytes + 2 * n_obj + 4)
@@ -451,11 +492,18 @@ def main():
             try:
                 with open(pmc) as f:
                     rec = json.load(f)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from make_pmc_record import kernel_source_sha
                 if rec.get("envs") == B and rec.get("obs_bytes") == eng.obs_bytes and \
                         rec.get("kernel") == eng.render_kernel and not args.fused:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "recorded: profiles/pmc_render_latest.json (rocprofv3 --pmc passes of " \
-                                     + str(rec.get("source", "an earlier run")) + "), not measured in this run"
+                    if rec.get("kernel_source_sha16") == kernel_source_sha():
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_source = "recorded: profiles/pmc_render_latest.json (rocprofv3 --pmc passes of " \
+                                         + str(rec.get("source", "an earlier run")) + ", head " + str(rec.get("git_head")) \
+                                         + ", same kernel source), not measured in this run"
+                    else:  # a record of an older kernel describes nothing
+                        traffic_source = "profiles/pmc_render_latest.json is stale (measured on another version of " \
+                                         "pw_render_kernels.inc); re-run tools/collect_profiles.sh"
             except Exception:  # noqa: BLE001
                 traffic = None
         kname = eng.render_kernel
@@ -478,7 +526,15 @@ def main():
             "launches_timed": int(len(ms)),
             "timer": "HIP events recorded by the library around the launch, on the launch stream (rank 0)",
             "rest_of_step_ms": 1000.0 * elapsed / K - float(ms.mean()),  # step kernel + launch gaps
+            # the same kernel on every rank (its own HIP events): fraction of the 8 TB/s peak per GPU
+            "per_rank_avg_launch_ms": [r[0] for r in rank_rows],
+            "per_rank_frac": [algo / (r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS for r in rank_rows],
         }
+        out["config"]["render_launch"]["per_rank"] = [
+            {"tuned_ms": round(r[3], 4), "allocations_tried": int(r[4]), "fast_class": bool(r[5])} for r in rank_rows]
+        slow = [i for i, r in enumerate(rank_rows) if not r[5]]
+        if slow:
+            out["config"]["render_launch"]["ranks_without_a_fast_buffer"] = slow
         out["config"]["algorithmic_bytes_per_env_step"] = eng.obs_bytes + state_bytes
     else:
         ms = np.array([a.elapsed_time(b) for a, b in step_events], dtype=np.float64)
@@ -491,8 +547,36 @@ def main():
             "median_launch_ms": float(np.median(ms)), "min_launch_ms": float(ms.min()), "launches_timed": int(len(ms)),
             "timer": "HIP events on the launch stream (torch current stream), rank 0",
             "note": "state-only steps are latency / issue bound, far below the HBM roofline by construction",
+            "per_rank_avg_launch_ms": [r[0] for r in rank_rows],
+            "per_rank_frac": [algo / (r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS for r in rank_rows],
         }
         out["config"]["algorithmic_bytes_per_env_step"] = state_bytes
+
+    # Scaling efficiency against the N = 1 run of the same workload: value / (N x the N = 1 value).  An N = 1 run
+    # leaves its value in profiles/bench_n1_latest.json (the driver runs N = 1, 2, 4, 8 back to back from one
+    # directory; otherwise the committed record of the last session is used and says so).
+    sig = {"config": args.config, "obs": args.obs, "envs_per_gpu": B, "ppc": args.ppc, "bw": args.bw, "max_steps": args.max_steps}
+    n1_path = os.path.join(ROOT, "profiles", "bench_n1_latest.json")
+    if world == 1 and not args.shared_device:
+        try:
+            with open(n1_path, "w") as f:
+                json.dump({"signature": sig, "value": out["value"], "ms_per_step": out["ms_per_step"], "unix_time": time.time(),
+                           "host": socket.gethostname(), "git_head": git_head()}, f, indent=1)
+        except OSError:
+            pass
+    else:
+        try:
+            with open(n1_path) as f:
+                rec = json.load(f)
+            if rec.get("signature") == sig and rec.get("value", 0) > 0:
+                same = rec.get("host") == socket.gethostname() and time.time() - rec.get("unix_time", 0) < 6 * 3600
+                out["scaling_efficiency"] = {
+                    "value": out["value"] / (world * rec["value"]), "n1_value": rec["value"],
+                    "n1_source": "profiles/bench_n1_latest.json: " + ("N = 1 run on this host %d s ago" % (time.time() - rec["unix_time"])
+                                                                      if same else "committed record of an earlier session (head %s)" % rec.get("git_head")),
+                }
+        except (OSError, ValueError):
+            pass
 
     if not args.no_extras:
         # extra (not the headline): the same loop with the observation buffer maintained incrementally

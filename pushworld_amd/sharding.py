@@ -71,6 +71,59 @@ def gather_floats(value: float, device=None):
     return [float(t.item()) for t in out]
 
 
+def gather_vectors(values, device=None):
+    """A fixed-length list of floats of every rank, in rank order (``[values]`` without a process group)."""
+    dist = _group()
+    if dist is None:
+        return [[float(v) for v in values]]
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(v) for v in t.tolist()] for t in out]
+
+
+def device_numa_cpus(device_index: int):
+    """(NUMA node, CPU set) local to a HIP device, from its PCI address in sysfs; (None, None) when unknown."""
+    import os
+
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        addr = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        base = os.path.join("/sys/bus/pci/devices", addr)
+        with open(os.path.join(base, "numa_node")) as f:
+            node = int(f.read().strip())
+        with open(os.path.join(base, "local_cpulist")) as f:
+            text = f.read().strip()
+        cpus = set()
+        for part in text.split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return (node if node >= 0 else None), (cpus or None)
+    except Exception:  # noqa: BLE001 -- no sysfs entry, old torch without the PCI fields, ...
+        return None, None
+
+
+def pin_to_device_numa(device_index: int):
+    """Pins the calling thread (the one that launches the kernels: the launch rate is host bound at ~8 us per
+    launch) to the CPUs of the device's NUMA node.  Returns (node or None, previous affinity mask or None)."""
+    import os
+
+    node, cpus = device_numa_cpus(device_index)
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return None, None
+    try:
+        before = os.sched_getaffinity(0)
+        allowed = cpus & before
+        if not allowed:
+            return None, None
+        os.sched_setaffinity(0, allowed)
+        return node, before
+    except OSError:
+        return None, None
+
+
 def reduce_counters(counters: Dict[str, int], elapsed_s: float, device=None) -> Tuple[Dict[str, int], float]:
     """SUM of integer counters and MAX of the elapsed time over all ranks (identity when
     torch.distributed is not initialised)."""

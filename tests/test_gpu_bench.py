@@ -30,6 +30,10 @@ def test_self_spawned_two_ranks_sum_their_counters():
     import torch
 
     shared = [] if torch.cuda.device_count() >= 2 else ["--shared-device"]
+    # an N = 1 run of the same workload first: it leaves the reference value of `scaling_efficiency`
+    proc1, lines1 = run_bench(*SMALL, "--no-cpu-baseline")
+    assert proc1.returncode == 0 and len(lines1) == 1, proc1.stderr[-2000:]
+    assert "scaling_efficiency" not in lines1[0] and len(lines1[0]["roofline"]["per_rank_frac"]) == 1
     proc, lines = run_bench("--gpus", "2", *shared, *SMALL, "--cpu-seconds", "1")
     assert proc.returncode == 0, proc.stderr[-2000:]
     assert len(lines) == 1, proc.stdout[-2000:]
@@ -40,9 +44,20 @@ def test_self_spawned_two_ranks_sum_their_counters():
     assert abs(d["value"] - 2 * 2048 * 3 / (d["ms_per_step"] * 3 / 1000.0)) < 1e-6 * d["value"]
     assert len(d["timing"]["per_rank_median_ms_per_step"]) == 2 and len(d["timing"]["window_ms_per_step"]) == 2
     assert d["timing"]["min_ms_per_step"] <= d["ms_per_step"] <= d["timing"]["max_ms_per_step"]
+    # with two devices the RCCL branch must have run (init_process_group("nccl") + a probe all_reduce; a failure
+    # aborts the run with exit code 3, it never falls back)
     assert ("gloo" if shared else "nccl") in d["config"]["parallelism"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["launches_timed"] == 6 and r["traffic"] is None
+    # every rank reports its own dominant-kernel time, roofline fraction and what its allocator found
+    assert len(r["per_rank_frac"]) == 2 and all(0 < f < 1 for f in r["per_rank_frac"])
+    assert len(r["per_rank_avg_launch_ms"]) == 2 and r["per_rank_avg_launch_ms"][0] == pytest.approx(r["avg_launch_ms"])
+    pr = d["config"]["render_launch"]["per_rank"]
+    assert len(pr) == 2 and all(set(x) == {"tuned_ms", "allocations_tried", "fast_class"} for x in pr)
+    assert len(d["timing"]["numa_node_per_rank"]) == 2
+    se = d["scaling_efficiency"]
+    assert se["n1_value"] == pytest.approx(lines1[0]["value"]) and "on this host" in se["n1_source"]
+    assert se["value"] == pytest.approx(d["value"] / (2 * lines1[0]["value"]))
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["one_thread"]["cores"] == 1 and cb["cpu_model"]
     assert cb["python_env"]["value"] > 0 and cb["python_env"]["processes"]["cores"] >= 1

@@ -334,10 +334,11 @@ def test_batch_beyond_2_31_chunks():
     torch.cuda.empty_cache()
 
 
-def _compare_all_envs(vec, oracles, ids, acts, max_steps, frame, n_obs, obs_steps):
+def _compare_all_envs(vec, oracles, ids, acts, max_steps, frame, n_obs, obs_steps, ppc=3, bw=1, dtype="u8"):
     """Every environment, every step: positions, float64 reward bits, terminated, truncated, step counter
     against the C oracle's trace (OpenMP over environments, next-step autoreset); full observations of
-    ``n_obs`` environments spread over the batch at the steps ``obs_steps``."""
+    ``n_obs`` environments spread over the batch at the steps ``obs_steps`` (``ppc`` / ``bw`` / ``dtype``: the
+    engine's observation settings)."""
     import torch
 
     from oracle import c_oracle
@@ -360,10 +361,62 @@ def _compare_all_envs(vec, oracles, ids, acts, max_steps, frame, n_obs, obs_step
         resets += int((want_steps[t] == 0).sum())
         if t in obs_steps:
             got = obs[torch.as_tensor(sel).to(vec.device)].cpu().numpy()
-            want = c_oracle.observe_batch(oracles, ids, want_pos[t], sel, frame[0], frame[1], 3, 1)
+            want = c_oracle.observe_batch(oracles, ids, want_pos[t], sel, frame[0], frame[1], ppc, bw, dtype)
+            assert got.dtype == want.dtype and got.shape == want.shape
             diff = np.nonzero((got != want).any(axis=(1, 2, 3)))[0]
             assert diff.size == 0, (t, sel[diff[:5]])
     return resets, len(sel)
+
+
+@pytest.mark.parametrize("obs,ppc,bw,B,n_obs,kernel", [
+    ("float32", 20, 2, 2048, 256, "pw_render_rowpage_kernel"),  # the reference's default observation, 10.3 MB each
+    ("uint8", 20, 2, 4096, 256, "pw_render_rowpage_kernel"),    # 2 520-byte rows: the unaligned instance
+    ("uint8", 8, 2, 16384, 384, "pw_render_rowpage_kernel"),
+    ("float32", 3, 1, 32768, 512, "pw_render_page_kernel"),     # the float32 instance of the ppc-3 page kernel
+])
+def test_row_page_kernels_against_the_oracle_at_batch_scale(obs, ppc, bw, B, n_obs, kernel):
+    """The page-ordered kernels of every setting other than uint8 / ppc 3, on the Level-1 mix at batch scale, pinned to
+    the ORACLE directly (puzzle.py:596-638, env_utils.py:65-91): every environment's state at every step with next-step
+    autoresets inside the window, and >= 256 complete observations per setting at three steps; then the same
+    observations for in-bounds OVERLAPPING states (every object at the position of its neighbour in the state vector:
+    painter order, puzzle.py:453-458)."""
+    import torch
+
+    import bench
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    paths = bench.level1_paths()
+    texts = [open(p).read() for p in paths]
+    T, max_steps = 8, 5
+    ids = (np.arange(B, dtype=np.int64) * len(paths)) // B
+    vec = VecPushWorld([PushWorldPuzzle(text=t) for t in texts], B, puzzle_ids=ids, max_steps=max_steps,
+                       pixels_per_cell=ppc, border_width=bw, observation=obs, device=0, autoreset=True, fused=True)
+    assert vec.engine.obs_shape == (51 * ppc, 42 * ppc, 3) and vec.engine.render_kernel == kernel
+    oracles = [c_oracle.COraclePuzzle(t) for t in texts]
+    acts = np.random.default_rng(17 + ppc).integers(0, 4, size=(T, B), dtype=np.uint8)
+    dt = "f32" if obs == "float32" else "u8"
+    resets, n_sel = _compare_all_envs(vec, oracles, ids, acts, max_steps, (51, 42), n_obs, (0, 5, T - 1), ppc, bw, dt)
+    assert resets >= B and n_sel >= min(n_obs, 256)
+    # overlapping states: object j at the position of object j - 1 (clamped into the grid by its own bounding box)
+    pos = vec.states()
+    over = pos.copy()
+    for b in range(B):
+        pz = oracles[int(ids[b])]
+        n = pz.num_movables
+        for j in range(1, n):
+            w = max(c[0] for c in pz.py.shapes[j]) + 1
+            h = max(c[1] for c in pz.py.shapes[j]) + 1
+            over[b, j, 0] = min(int(pos[b, j - 1, 0]), pz.width - w)
+            over[b, j, 1] = min(int(pos[b, j - 1, 1]), pz.height - h)
+    vec.set_states(over)
+    got_all = vec.render()
+    sel = np.unique(np.linspace(0, B - 1, min(n_obs, 256)).astype(np.int64))
+    got = got_all[torch.as_tensor(sel).to(vec.device)].cpu().numpy()
+    want = c_oracle.observe_batch(oracles, ids, over, sel, 51, 42, ppc, bw, dt)
+    diff = np.nonzero((got != want).any(axis=(1, 2, 3)))[0]
+    assert diff.size == 0, sel[diff[:5]]
 
 
 def test_c3_every_environment_against_the_oracle():

@@ -22,8 +22,8 @@ def _worker(rank, world, port, total, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
-    from pushworld_amd.sharding import (c4_global_puzzle_ids, gather_floats, reduce_counters, reduce_max, shard_bounds,
-                                        shard_puzzle_ids)
+    from pushworld_amd.sharding import (c4_global_puzzle_ids, gather_floats, gather_vectors, reduce_counters, reduce_max,
+                                        shard_bounds, shard_puzzle_ids)
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,6 +36,8 @@ def _worker(rank, world, port, total, out_dir):
     # bench.py's per-window MAX over ranks and per-rank report
     wmax = reduce_max([1.0 + rank, 5.0 - rank])
     per_rank = gather_floats(10.0 * (rank + 1))
+    rows = gather_vectors([rank + 0.5, 7.0, -1.0 - rank])  # bench.py's per-rank report rows
+    assert rows == [[0.5, 7.0, -1.0], [1.5, 7.0, -2.0]], rows
     # config C4: every rank derives the same global assignment and keeps its own slice
     glob = c4_global_puzzle_ids(total, 14000, 223, 100)
     c4_mine = np.sort(shard_puzzle_ids(glob, rank, world))
@@ -88,6 +90,9 @@ def test_c4_assignment_is_rank_independent_and_balanced():
     parts = [shard_puzzle_ids(g, r, 8) for r in range(8)]
     assert all(len(p) == 65536 for p in parts) and (np.concatenate(parts) == g).all()
     assert reduce_max([1.0, 2.0]) == [1.0, 2.0] and gather_floats(3.0) == [3.0]
+    from pushworld_amd.sharding import gather_vectors, pin_to_device_numa
+    assert gather_vectors([1.0, 2.5]) == [[1.0, 2.5]]       # no process group: this rank only
+    assert pin_to_device_numa(0) == (None, None)             # no HIP device here: nothing is pinned
     with pytest.raises(ValueError):
         c4_global_puzzle_ids(10, 0, 223)
 

@@ -5,9 +5,30 @@ counts the 128-byte requests of a wide coalesced read as 64 bytes on gfx950, so 
 
     python tools/make_pmc_record.py fetch_results.db write_results.db KERNEL_SUBSTRING envs obs_bytes source > record.json
 """
+import hashlib
 import json
+import os
 import sqlite3
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCE = os.path.join(ROOT, "pushworld_amd", "csrc", "pw_render_kernels.inc")
+
+
+def kernel_source_sha():
+    """sha256 of the render kernels' source: bench.py copies a record into its line only for the source it was
+    measured on."""
+    with open(KERNEL_SOURCE, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def mean_counter(db, kernel, counter):
@@ -18,7 +39,7 @@ def mean_counter(db, kernel, counter):
     best = None
     for name, val, n in rows:
         # the production symbol only (kTag = 0), not the tuner's trial launches (kTag = 1)
-        if kernel in name and ", 1>" not in name and (best is None or n > best[2]):
+        if kernel in name and ", 1>" not in name and ", 1," not in name and (best is None or n > best[2]):
             best = (name, val, n)
     if best is None:
         raise SystemExit(f"{counter}: no kernel matching {kernel!r} in {db}")
@@ -39,6 +60,8 @@ def main():
         "fetch_size_kb_raw": fetch_kb,
         "dispatches": [fn, wn],
         "source": source,
+        "kernel_source_sha16": kernel_source_sha(),
+        "git_head": git_head(),
         "note": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, --kernel-trace only), mean over the "
                 "dispatches of the kernel on the C3 workload; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
                 "tallies 128-B requests as 64 B)",
