@@ -165,6 +165,9 @@ typedef struct PwGenConfig {   /* generate_level0_puzzles, generate.py:136-259 (
  * device < 0: the same function on the host (host buffers) -- identical output. */
 int pw_generate_level0(int device, const PwGenConfig* cfg, uint64_t first, int32_t count, uint8_t* grids,
                        int32_t* dims, void* stream);
+/* Host only, for the distribution tests: failed[i] = how many generate_puzzle attempts of puzzle first + i raised
+ * FailedToGenerateError (generate.py:236-257 retries silently) before the one that was kept; 1000 = gave up. */
+int pw_generate_level0_attempts(const PwGenConfig* cfg, uint64_t first, int32_t count, int32_t* failed);
 /* The 8 dihedral variants of every grid (transform.py:21-48): out uint8 [count][8][slot_w * slot_w], out_dims int32
  * [count][8][2]; variant v = 4 * flipped + clockwise quarter turns (names r0 r90 r180 r270 r0_flipped ...), the
  * top-bottom flip applied before the rotation. */

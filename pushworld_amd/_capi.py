@@ -132,6 +132,7 @@ SIGNATURES = {
     ),
     "pw_expand4": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "pw_generate_level0": (c_int, [c_int, POINTER(PwGenConfig), ctypes.c_uint64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "pw_generate_level0_attempts": (c_int, [POINTER(PwGenConfig), ctypes.c_uint64, c_int32, c_void_p]),
     "pw_transform_grids": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "pw_puzzleset_from_grids": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int, POINTER(c_void_p), c_void_p]),
     "pw_grid_to_text": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_char_p, c_int32]),
