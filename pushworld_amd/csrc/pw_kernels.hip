@@ -98,6 +98,7 @@ struct PwEngine {
   PwOvlDir* d_ovl_dir;     // [set size]
   int64_t ovl_bytes;
   int ovl_puzzles;         // puzzles with tables
+  std::vector<uint8_t> ovl_has;  // [set size] host copy: puzzle p has tables
   // launch configuration of the page-ordered render kernel (CopyArgs::order / run_log2, dynamic LDS as an
   // occupancy cap); defaults are the robust optimum, pw_engine_tune_render measures the caller's buffer
   int page_order, page_run_log2, page_lds_pad_kb;

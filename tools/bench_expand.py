@@ -28,9 +28,13 @@ def frontier(pz, target):
 
 
 def main():
-    for rel, target in [("level1/2 Obstacle.pwp", 200000), ("level2/Pull Dont Push.pwp", 200000),
-                        ("level4/Four Pistons.pwp", 200000)]:
+    cases = [(rel, 200000, mode) for rel in ("level1/2 Obstacle.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp")
+             for mode in ("big", "all")]
+    cases += [("level4/Mind The Gap.pwp", 200000, "none"), ("level4/Mind The Gap.pwp", 200000, "big")]
+    for rel, target, mode in cases:
         pz = PushWorldPuzzle(os.path.join(BENCHMARK_PUZZLES_PATH, rel), order="cpp")
+        pz._engine().set_option("step_tables", mode)  # PW_OPT_STEP_TABLES
+        rel = "%s [tables %s]" % (rel, mode)
         t0 = time.time()
         st = frontier(pz, target)
         reps = max(1, 1_000_000 // len(st))
@@ -50,7 +54,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         algo = F * (20 * N + 20)
-        print(f"{rel:28s} N={N:2d} distinct={len(st):7d} F={F:8d}  {ms:7.3f} ms  {F / ms * 1e3:11.3e} parents/s  "
+        print(f"{rel:44s} N={N:2d} distinct={len(st):7d} F={F:8d}  {ms:7.3f} ms  {F / ms * 1e3:11.3e} parents/s  "
               f"{4 * F / ms * 1e3:11.3e} successors/s  {algo / ms / 1e6:7.1f} GB/s algorithmic  (frontier build {time.time() - t0:.1f}s)",
               flush=True)
 
