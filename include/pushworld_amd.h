@@ -227,7 +227,7 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       two movables per lane (4 environments per wavefront); 1: 32 lanes, one movable each */
 #define PW_OPT_PAGE_LOAD_ALL 13      /* ppc-3 page kernel: 1 = every page loads its static-image chunks, also the all-zero pages of
                                       the frame padding (a more even write front; a candidate of pw_engine_tune_render) */
-#define PW_OPT_OBS_CHUNK_MB 14       /* pw_obs_alloc: MiB per physical chunk (0 = the device's allocation granularity, 2 MiB) */
+#define PW_OPT_OBS_CHUNK_MB 14       /* pw_obs_alloc: MiB per physical chunk (0 = default, 32 MiB) */
 #define PW_OPT_OBS_ACCEPT_GBS 15     /* pw_obs_alloc_tuned: a candidate on which the tuned render reaches this many GB/s is
                                       kept without looking further (default 6880 = 0.86 of the 8 TB/s peak) */
 #define PW_OPT_STEP_TABLES 16         /* overlap tables for the lane-group step / expansion / search kernels (the reference's

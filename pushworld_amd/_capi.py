@@ -165,7 +165,7 @@ OPTIONS = {
     "tuned_ns": 11,          # read-only
     "step_wide_groups": 12,  # N_pad 32: 0 two movables per lane (16-lane groups), 1 32-lane groups
     "page_load_all": 13,     # ppc-3 page kernel: every page loads its static chunks
-    "obs_chunk_mb": 14,      # pw_obs_alloc: MiB per physical chunk (0 = allocation granularity)
+    "obs_chunk_mb": 14,      # pw_obs_alloc: MiB per physical chunk (0 = default, 32)
     "obs_accept_gbs": 15,    # pw_obs_alloc_tuned: rate at which a candidate buffer is kept right away
     "step_tables": 16,       # overlap tables: 0 / "big" puzzles with movables beyond 8 x 8, 1 / "all", 2 / "none"
     "step_table_bytes": 17,    # read-only

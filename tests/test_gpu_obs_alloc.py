@@ -46,7 +46,6 @@ def test_owned_buffer_is_adopted_in_place_and_freed_to_the_device(torch_mod):
     eng = vec.engine
     torch.cuda.synchronize()
     reserved0 = torch.cuda.memory_reserved()
-    free0 = torch.cuda.mem_get_info()[0]
     for cycle in range(3):
         st, view = eng.alloc_obs_owned(vec.num_envs)
         assert st.device == vec.device and st.dtype == torch.uint8 and tuple(view.shape) == tuple(ref.shape)
@@ -54,15 +53,21 @@ def test_owned_buffer_is_adopted_in_place_and_freed_to_the_device(torch_mod):
         eng.render(vec.puzzle_id, vec.pos, st)
         torch.cuda.synchronize()
         assert torch.equal(view, ref)
-        assert torch.cuda.mem_get_info()[0] < free0  # the memory is taken from the device ...
-        assert torch.cuda.memory_reserved() == reserved0  # ... not from torch's allocator
+        assert torch.cuda.memory_reserved() == reserved0  # the memory is the device's, not torch's allocator's
         sub = view[3]  # a view keeps the buffer alive
         del st, view
         gc.collect()
         assert torch.equal(sub, ref[3])
         del sub
         gc.collect()
-        assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)  # released to the device
+    # released to the DEVICE: 40 buffers of 8.7 GB one after the other are more than the 288 GB of HBM
+    # (hipMemGetInfo cannot be asked: it reports 0 free bytes while virtual-memory mappings exist)
+    for cycle in range(40):
+        st, view = eng.alloc_obs_owned(150000)
+        st[-1].fill_(cycle)
+        assert int(st[-1, -1]) == cycle and int(st[0, 0]) == 0
+        del st, view
+    assert torch.cuda.memory_reserved() == reserved0
     # against the oracle, not only against the torch-owned buffer
     pos = vec.states()
     envs = [0, 1, 700, 2047]
@@ -82,7 +87,7 @@ def test_obs_free_rejects_foreign_pointers(torch_mod):
         _capi.check(_capi.lib.pw_obs_alloc(vec.engine.handle, 0, ctypes.byref(p)))
 
 
-@pytest.mark.parametrize("chunk_mb", [0, 32])
+@pytest.mark.parametrize("chunk_mb", [0, 8])
 def test_tuned_allocation_tries_candidates_and_releases_the_losers(torch_mod, chunk_mb):
     torch = torch_mod
     vec, texts, ids = _level1(4096, tune=False, engine_options={"obs_chunk_mb": chunk_mb})
@@ -91,16 +96,13 @@ def test_tuned_allocation_tries_candidates_and_releases_the_losers(torch_mod, ch
     eng.set_option("obs_accept_gbs", 100000)  # out of reach: every candidate is tried unless one is 6 % faster
     torch.cuda.synchronize()
     reserved0 = torch.cuda.memory_reserved()
-    free0 = torch.cuda.mem_get_info()[0]
     st, view, idx, cand = eng.alloc_obs_tuned(vec.puzzle_id, vec.pos, 3)
     torch.cuda.synchronize()
     assert 1 <= len(cand) <= 3 and all(c > 0 for c in cand) and 0 <= idx < 20
     assert torch.equal(view, ref)
     assert eng.get_option("tuned_ns") == pytest.approx(min(cand) * 1e6, rel=1e-3)
     assert torch.cuda.memory_reserved() == reserved0
-    nbytes = vec.num_envs * eng.obs_stride
-    # one buffer stays (rounded up to whole chunks), the losers are back on the device
-    assert free0 - torch.cuda.mem_get_info()[0] <= nbytes + (64 << 20)
+    assert len(cand) >= 2  # 4 096 environments never reach the accept rate: at least two candidates were tuned
     # stepping into the owned buffer
     g = torch.Generator(device=vec.device).manual_seed(11)
     for _ in range(6):
@@ -113,6 +115,13 @@ def test_tuned_allocation_tries_candidates_and_releases_the_losers(torch_mod, ch
     envs = [0, 5, 1234, 4095]
     want = _oracle_obs(texts, ids, vec.states(), envs, ref.shape[1] // 3, ref.shape[2] // 3)
     assert np.array_equal(view[envs].cpu().numpy(), want)
+    # again and again: candidates come and go (the losers' memory returns to the device, their address ranges stay)
+    del st, view
+    for _ in range(4):
+        st, view, idx, cand = eng.alloc_obs_tuned(vec.puzzle_id, vec.pos, 3)
+        assert torch.equal(view, vec.obs)
+        del st, view
+    assert torch.cuda.memory_reserved() == reserved0
 
 
 def test_vec_env_binds_its_observation_once(torch_mod):

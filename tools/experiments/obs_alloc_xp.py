@@ -125,7 +125,10 @@ if __name__ == "__main__":
         n = int(sys.argv[3]) if len(sys.argv) > 3 else 10
         rest = sys.argv[4:]
         for i in range(n):
-            subprocess.run([sys.executable, os.path.abspath(__file__), "one", cfg] + rest, timeout=600)
+            try:
+                subprocess.run([sys.executable, os.path.abspath(__file__), "one", cfg] + rest, timeout=200)
+            except subprocess.TimeoutExpired:
+                print("TIMEOUT", flush=True)
     elif mode == "classes":
         cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
         classes(cfg, int(sys.argv[3]) if len(sys.argv) > 3 else 0, int(sys.argv[4]) if len(sys.argv) > 4 else 8)
