@@ -54,6 +54,8 @@ def bfs(puzzle, max_states):
     # ... and tables for puzzles of small movables
     "bench:level1/2 Obstacle.pwp|all", "bench:level4/Four Pistons.pwp|all", "bench:level2/Clean Sweep.pwp|all",
     "cpptest:necessary_transitive_pushing3.pwp|all",
+    # 9 .. 16 movables: 8-lane groups with two movables per lane by default; "wide": one movable per lane, 16 lanes
+    "bench:level4/Four Pistons.pwp|wide", "bench:level4/Mind The Gap.pwp|wide", "bench:level1/Pulling.pwp|wide",
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle
@@ -64,7 +66,9 @@ def test_bfs_layers_match_oracle(golden, key):
         pytest.skip("puzzle not in the fixture set")
     text = golden.text(key)
     pz = PushWorldPuzzle(text=text, order="cpp")
-    if tables:
+    if tables == "wide":
+        pz._engine().set_option("step_wide_groups", 1)
+    elif tables:
         pz._engine().set_option("step_tables", tables)
         assert (pz._engine().get_option("step_table_puzzles") == 1) == (tables == "all")
     oz = c_oracle.COraclePuzzle(text, order="cpp")
