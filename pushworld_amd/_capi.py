@@ -170,6 +170,7 @@ OPTIONS = {
     "step_tables": 16,       # overlap tables: 0 / "big" puzzles with movables beyond 8 x 8, 1 / "all", 2 / "none"
     "step_table_bytes": 17,    # read-only
     "step_table_puzzles": 18,  # read-only
+    "step_narrow_groups": 19,  # N_pad 16: 8-lane groups with two movables per lane
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 0, "all": 1, "none": 2}
 

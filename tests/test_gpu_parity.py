@@ -29,8 +29,10 @@ def puzzles(golden):
 
 
 def _groups(golden):
-    g = {"bench": [], "tests": [], "l0": []}
+    g = {"bench": [], "tests": [], "l0": [], "level1": []}
     for k in golden.keys:
+        if k.startswith("bench:level1/"):
+            g["level1"].append(k)  # at most 11 movables: an N_pad 16 pool (also part of "bench")
         if k.startswith("bench:"):
             g["bench"].append(k)
         elif k.startswith("l0:"):
@@ -45,6 +47,8 @@ def _step_options(kernel):
     steps; pools with more than 16 movables per puzzle: two per lane), "group-lds" (row tables staged in LDS, the
     default of multi-step rollouts), "group-wide" (32-lane groups), "lane", "wave"; "group-tables" / "group-notables":
     overlap tables (PW_OPT_STEP_TABLES) for every puzzle / for none (default: for puzzles with movables beyond 8 x 8)."""
+    if kernel == "group-narrow":  # N_pad 16 pools: 8 lanes per environment, two movables per lane
+        return {"step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 1}
     if kernel == "group-tables":
         return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "all"}
     if kernel == "group-notables":
@@ -61,6 +65,7 @@ def _step_options(kernel):
                                           ("bench", "group-wide"),
                                           ("bench", "group-tables"), ("tests", "group-tables"), ("l0", "group-tables"),
                                           ("bench", "group-notables"), ("tests", "group-notables"),
+                                          ("level1", "group"), ("level1", "group-narrow"), ("level1", "group-lds"),
                                           ("bench", "lane"), ("tests", "lane"), ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
