@@ -188,7 +188,7 @@ int pw_puzzleset_headers(const PwPuzzleSet* s, const void** data, size_t* bytes)
  *   pair table (i, j), R rows:  bit (rx + w_i - 1) of row (ry + h_i - 1) = movable i at (rx, ry) relative to movable j
  *                               overlaps it;  "i pushes j with displacement d" = overlap at r + d and not at r
  *   wall table j, H + 2 rows:   bit (x + 1) of row (y + 1) = movable j at (x, y) overlaps a wall (j = 0: or agent wall)
- * dir: uint32 [count][4] = {pair_off, wall_off, R | (H + 2) << 16, 0} in 8-byte words (pair_off 0 = no tables; pair
+ * mode: as PW_OPT_STEP_TABLES.  dir: uint32 [count][4] = {pair_off, wall_off, R | (H + 2) << 16, 0} in 8-byte words (pair_off 0 = no tables; pair
  * table (i, j) at pair_off + (i * N + j) * R, wall table j at wall_off + j * (H + 2)).  Returns the number of words
  * (writes them when cap_words suffices). */
 int64_t pw_puzzleset_overlap_tables(const PwPuzzleSet* s, int mode, uint64_t* words, int64_t cap_words, uint32_t* dir);
@@ -232,9 +232,11 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       kept without looking further (default 6880 = 0.86 of the 8 TB/s peak) */
 #define PW_OPT_STEP_TABLES 16         /* overlap tables for the lane-group step / expansion / search kernels (the reference's
                                       collision tables, puzzle.py:259-311, with the four actions sharing one table; one or two
-                                      8-byte loads instead of a loop over object rows): 0 (default) for puzzles with a movable
-                                      beyond 8 x 8 cells, 1 for every puzzle, 2 none.  Setting it rebuilds the tables
-                                      (synchronises the device) */
+                                      8-byte loads instead of a loop over object rows): 0 (default) automatic -- for EVERY puzzle
+                                      of the set as soon as one has a movable beyond 8 x 8 cells (the kernels then carry no row
+                                      loops at all), otherwise none; 1 every puzzle; 2 none; 3 only the puzzles with such
+                                      movables (kernels with both paths).  Setting it rebuilds the tables (synchronises the
+                                      device) */
 #define PW_OPT_STEP_TABLE_BYTES 17   /* read-only: bytes of overlap tables in HBM */
 #define PW_OPT_STEP_TABLE_PUZZLES 18 /* read-only: puzzles of the set that have overlap tables */
 #define PW_OPT_STEP_NARROW_GROUPS 19 /* sets with 9..16 movables per puzzle (N_pad 16): 1 = 8 lanes per environment, two movables per
@@ -269,9 +271,8 @@ int pw_engine_tune_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* p
  *                       THE OTHERS TO THE DEVICE.  The kept buffer holds the observations of (puzzle_id, pos), the engine
  *                       its tuned launch configuration; returns the tuner's index (>= 0).  candidate_ms (host float
  *                       [max_candidates], may be NULL) receives every candidate's tuned time, *tried how many were made.
- *   pw_obs_free         unmaps the buffer and releases its memory to the device (synchronises the device first).
- *                       pw_engine_destroy frees what is left.  The address range of a freed buffer stays reserved
- *                       until the process ends (an address range costs no memory). */
+ *   pw_obs_free         unmaps the buffer, releases its memory to the device and frees its address range (synchronises
+ *                       the device first).  pw_engine_destroy frees what is left. */
 int pw_obs_alloc(PwEngine* e, int32_t batch, void** obs);
 int pw_obs_alloc_tuned(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, int32_t batch, int32_t max_candidates,
                        void** obs, float* candidate_ms, int32_t* tried, void* stream);

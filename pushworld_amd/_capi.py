@@ -167,12 +167,12 @@ OPTIONS = {
     "page_load_all": 13,     # ppc-3 page kernel: every page loads its static chunks
     "obs_chunk_mb": 14,      # pw_obs_alloc: MiB per physical chunk (0 = default, 32)
     "obs_accept_gbs": 15,    # pw_obs_alloc_tuned: rate at which a candidate buffer is kept right away
-    "step_tables": 16,       # overlap tables: 0 / "big" puzzles with movables beyond 8 x 8, 1 / "all", 2 / "none"
+    "step_tables": 16,       # overlap tables: 0 / "auto" (all puzzles if any has a movable beyond 8 x 8), 1 / "all", 2 / "none", 3 / "big"
     "step_table_bytes": 17,    # read-only
     "step_table_puzzles": 18,  # read-only
     "step_narrow_groups": 19,  # N_pad 16: 8-lane groups with two movables per lane
 }
-_OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 0, "all": 1, "none": 2}
+_OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2}
 
 
 def _load():

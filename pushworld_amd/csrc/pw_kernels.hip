@@ -54,11 +54,12 @@ struct PwOvlDir {
 };
 
 // An observation buffer owned by the library (pw_obs_alloc): one reserved address range backed by physical chunks
-// created and mapped with the HIP virtual-memory API.  Unmapped and released to the DEVICE by pw_obs_free /
-// pw_engine_destroy (not to a caching allocator); the address range itself is never handed back (see pw_obs_free).
+// created and mapped with the HIP virtual-memory API.  Unmapped, released and its address range freed by pw_obs_free /
+// pw_engine_destroy: the memory goes back to the DEVICE, not to a caching allocator.
 struct PwObsBuf {
   void* ptr;
   size_t bytes;   // mapped bytes (a multiple of the chunk size)
+  size_t reserved;  // bytes of the reserved address range (0: none)
   size_t chunk;
   std::vector<hipMemGenericAllocationHandle_t> handles;
 };

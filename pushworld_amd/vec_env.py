@@ -115,8 +115,8 @@ class VecPushWorld:
             if tune is None:
                 tune = nbytes >= (256 << 20)
             if tune and tune_allocations is None:  # as many as fit into a quarter of the device memory, at most 4
-                # (of the TOTAL memory: hipMemGetInfo reports 0 free bytes on this runtime while virtual-memory
-                # mappings exist; the library chooses among the candidates there are when memory runs out)
+                # (of the TOTAL memory: torch.cuda.mem_get_info() was seen returning 0 free bytes on these boxes;
+                # the library chooses among the candidates there are when memory runs out)
                 total = torch.cuda.get_device_properties(self.device).total_memory
                 tune_allocations = min(4, max(1, int(total // 4 // nbytes)))
             if tune and tune_allocations:

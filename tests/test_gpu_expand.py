@@ -48,7 +48,7 @@ def bfs(puzzle, max_states):
     "bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp", "bench:level4/Four Pistons.pwp",
     "bench:level1/Pulling.pwp", "bench:level3/Armor.pwp",
     "bench:level2/Clean Sweep.pwp",  # 19 movables: the 32-lane instantiation
-    # movables beyond 8 x 8 cells: overlap tables by default (PW_OPT_STEP_TABLES), the row loops with "none"
+    # movables beyond 8 x 8 cells: overlap tables by default (PW_OPT_STEP_TABLES, automatic), the row loops with "none"
     "bench:level4/Mind The Gap.pwp", "bench:level4/Mind The Gap.pwp|none", "bench:level2/Bubbles.pwp",
     "bench:level3/Rocky Shore.pwp", "bench:level3/Rocky Shore.pwp|none", "bench:level3/Moving Mountains.pwp",
     # ... and tables for puzzles of small movables

@@ -51,6 +51,10 @@ def _step_options(kernel):
         return {"step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 1}
     if kernel == "group-tables":
         return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "all"}
+    if kernel == "group-bigtables":  # tables only for the puzzles with big movables: the kernel instance with both paths
+        return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "big"}
+    if kernel == "group-bigtables-lds":
+        return {"step_kernel": "group", "step_lds_tables": 1, "step_tables": "big"}
     if kernel == "group-notables":
         return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "none"}
     if kernel == "group-lds":
@@ -65,6 +69,7 @@ def _step_options(kernel):
                                           ("bench", "group-wide"),
                                           ("bench", "group-tables"), ("tests", "group-tables"), ("l0", "group-tables"),
                                           ("bench", "group-notables"), ("tests", "group-notables"),
+                                          ("bench", "group-bigtables"), ("bench", "group-bigtables-lds"),
                                           ("level1", "group"), ("level1", "group-narrow"), ("level1", "group-lds"),
                                           ("bench", "lane"), ("tests", "lane"), ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
@@ -124,7 +129,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-tables", "group-notables", "lane", "wave"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-tables", "group-notables", "group-bigtables", "lane", "wave"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""

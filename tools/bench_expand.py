@@ -29,8 +29,8 @@ def frontier(pz, target):
 
 def main():
     cases = [(rel, 200000, mode) for rel in ("level1/2 Obstacle.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp")
-             for mode in ("big", "all")]
-    cases += [("level4/Mind The Gap.pwp", 200000, "none"), ("level4/Mind The Gap.pwp", 200000, "big")]
+             for mode in ("auto", "all")]
+    cases += [("level4/Mind The Gap.pwp", 200000, "none"), ("level4/Mind The Gap.pwp", 200000, "auto")]
     for rel, target, mode in cases:
         pz = PushWorldPuzzle(os.path.join(BENCHMARK_PUZZLES_PATH, rel), order="cpp")
         pz._engine().set_option("step_tables", mode)  # PW_OPT_STEP_TABLES

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """PW_OPT_STEP_TABLES A/B (state only, lane-group kernel): overlap tables for no puzzle / for the puzzles with movables
-beyond 8 x 8 (default) / for every puzzle.  One step per launch (median / min microseconds over --reps launches, HIP
+beyond 8 x 8 only (kernel with both paths) / automatic = the default (every puzzle of a set that has such a movable:
+the table-only kernel; none for sets without).  One step per launch (median / min microseconds over --reps launches, HIP
 events) and 64-step rollouts.  Workloads: C2, C3, the C4 shard, Levels 1-4 only, Levels 1-4 without the big-object puzzles,
 65 536 copies of Mind The Gap (the slowest puzzle of profiles/r02_step_xp.txt section 7)."""
 import argparse
@@ -82,13 +83,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--which", default="c2,c3,c4,l14,nobig,gap")
-    ap.add_argument("--modes", default="none,big,all")
+    ap.add_argument("--modes", default="none,big,auto,none+narrow,auto+narrow")
     args = ap.parse_args()
-    print("%-30s %-6s %9s %9s %13s %15s %10s" % ("workload", "tables", "step med", "step min", "rollout64 us", "rollout steps/s", "table KB"))
+    print("%-30s %-12s %9s %9s %13s %15s %10s" % ("workload", "tables", "step med", "step min", "rollout64 us", "rollout steps/s", "table KB"))
     for name, pool, B, ids in workloads(args.which.split(",")):
         for mode in args.modes.split(","):
-            vec = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=200, observation=None, autoreset=True,
-                               engine_options={"step_tables": mode})
+            opts = {"step_tables": mode.split("+")[0]}
+            if mode.endswith("+narrow"):
+                opts["step_narrow_groups"] = 1
+            vec = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=200, observation=None, autoreset=True, engine_options=opts)
             vec.reset()
             g = torch.Generator(device=vec.device).manual_seed(1)
             acts = torch.randint(0, 4, (64, B), generator=g, device=vec.device, dtype=torch.uint8)
@@ -100,7 +103,7 @@ def main():
 
             med, mn = timed(one, args.reps)
             rmed, _ = timed(lambda: vec.rollout(acts), max(10, args.reps // 5))
-            print("%-30s %-6s %9.2f %9.2f %13.1f %15.3e %10d" % (name, mode, med, mn, rmed, 64 * B / (rmed * 1e-6),
+            print("%-30s %-12s %9.2f %9.2f %13.1f %15.3e %10d" % (name, mode, med, mn, rmed, 64 * B / (rmed * 1e-6),
                                                                  vec.engine.get_option("step_table_bytes") >> 10), flush=True)
             del vec
 
