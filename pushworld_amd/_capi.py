@@ -171,8 +171,10 @@ OPTIONS = {
     "step_table_bytes": 17,    # read-only
     "step_table_puzzles": 18,  # read-only
     "step_narrow_groups": 19,  # N_pad 16: 8-lane groups with two movables per lane
+    "step_block_order": 20,    # 0 / "forward", 1 / "reverse": which end of the batch the step kernel starts with
 }
-_OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2}
+_OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2,
+                  "forward": 0, "reverse": 1}
 
 
 def _load():

@@ -101,6 +101,14 @@ class VecPushWorld:
             if ids.shape != (self.num_envs,) or ids.min() < 0 or ids.max() >= self.num_puzzles:
                 raise ValueError("puzzle_ids must be [num_envs] indices into the puzzle pool")
         self.puzzle_id = torch.as_tensor(ids, dtype=torch.int32).to(self.device)
+        if "step_block_order" not in (engine_options or {}) and self.num_envs >= 4096:
+            # A launch lasts as long as its slowest wavefronts: when the expensive puzzles (many movables) sit at the
+            # END of the batch (pools sorted by level), let the step kernel start there and the cheap ones fill the tail.
+            n_mov = np.frombuffer(self.pset.headers(), np.uint8).reshape(-1, 320)[:, 6].astype(np.float64)  # PwPuzzleHeader::N
+            cost = n_mov[np.asarray(ids, dtype=np.int64)]
+            q = max(1, self.num_envs // 4)
+            if cost[-q:].mean() > 1.15 * cost[:q].mean():
+                self.engine.set_option("step_block_order", "reverse")
         st = self.engine.alloc_state(self.num_envs)
         self.pos, self.steps = st["pos"], st["steps"]
         self.reward, self.dgoals = st["reward"], st["dgoals"]

@@ -83,14 +83,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--which", default="c2,c3,c4,l14,nobig,gap")
-    ap.add_argument("--modes", default="none,big,auto,none+narrow,auto+narrow")
+    ap.add_argument("--modes", default="none+fwd,auto+fwd,auto,all+fwd,all,all+narrow")
     args = ap.parse_args()
     print("%-30s %-12s %9s %9s %13s %15s %10s" % ("workload", "tables", "step med", "step min", "rollout64 us", "rollout steps/s", "table KB"))
     for name, pool, B, ids in workloads(args.which.split(",")):
         for mode in args.modes.split(","):
             opts = {"step_tables": mode.split("+")[0]}
-            if mode.endswith("+narrow"):
+            if "+narrow" in mode:
                 opts["step_narrow_groups"] = 1
+            if "+fwd" in mode:   # (VecPushWorld picks the reverse order by itself when the expensive puzzles come last)
+                opts["step_block_order"] = "forward"
+            if "+rev" in mode:
+                opts["step_block_order"] = "reverse"
             vec = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=200, observation=None, autoreset=True, engine_options=opts)
             vec.reset()
             g = torch.Generator(device=vec.device).manual_seed(1)
@@ -103,8 +107,9 @@ def main():
 
             med, mn = timed(one, args.reps)
             rmed, _ = timed(lambda: vec.rollout(acts), max(10, args.reps // 5))
-            print("%-30s %-12s %9.2f %9.2f %13.1f %15.3e %10d" % (name, mode, med, mn, rmed, 64 * B / (rmed * 1e-6),
-                                                                 vec.engine.get_option("step_table_bytes") >> 10), flush=True)
+            print("%-30s %-12s %9.2f %9.2f %13.1f %15.3e %10d%s" % (name, mode, med, mn, rmed, 64 * B / (rmed * 1e-6),
+                                                                   vec.engine.get_option("step_table_bytes") >> 10,
+                                                                   "  reverse" if vec.engine.get_option("step_block_order") else ""), flush=True)
             del vec
 
 
