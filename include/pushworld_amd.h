@@ -232,15 +232,16 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       kept without looking further (default 6880 = 0.86 of the 8 TB/s peak) */
 #define PW_OPT_STEP_TABLES 16         /* overlap tables for the lane-group step / expansion / search kernels (the reference's
                                       collision tables, puzzle.py:259-311, with the four actions sharing one table; one or two
-                                      8-byte loads instead of a loop over object rows): 0 (default) automatic -- for EVERY puzzle
-                                      of the set as soon as one has a movable beyond 8 x 8 cells (the kernels then carry no row
-                                      loops at all), otherwise none; 1 every puzzle; 2 none; 3 only the puzzles with such
-                                      movables (kernels with both paths).  Setting it rebuilds the tables (synchronises the
-                                      device) */
+                                      8-byte loads instead of a loop over object rows): 0 (default) and 1 every puzzle that fits
+                                      (grids up to 62 columns, movables up to 32 wide, 256 MB in all) -- when that is every puzzle
+                                      of the set the kernels carry no row loops at all; 2 none; 3 only the puzzles with a movable
+                                      beyond 8 x 8 cells (kernels with both paths).  Setting it rebuilds the tables (synchronises
+                                      the device) */
 #define PW_OPT_STEP_TABLE_BYTES 17   /* read-only: bytes of overlap tables in HBM */
 #define PW_OPT_STEP_TABLE_PUZZLES 18 /* read-only: puzzles of the set that have overlap tables */
-#define PW_OPT_STEP_NARROW_GROUPS 19 /* sets with 9..16 movables per puzzle (N_pad 16): 1 = 8 lanes per environment, two movables per
-                                      lane (8 environments per wavefront) instead of 16 lanes */
+#define PW_OPT_STEP_NARROW_GROUPS 19 /* sets with 9..16 movables per puzzle (N_pad 16): 8 lanes per environment, two movables per lane
+                                      (8 environments per wavefront) instead of 16 lanes: 0 automatic (launches of several steps
+                                      with the table-only kernels), 1 always, 2 never */
 #define PW_OPT_STEP_BLOCK_ORDER 20   /* lane-group step kernels: 0 workgroups take the environments in index order, 1 in reverse --
                                       for batches sorted by puzzle whose expensive puzzles (many / big movables) come last:
                                       they then start first and the cheap ones fill the tail of the launch */

@@ -167,7 +167,7 @@ OPTIONS = {
     "page_load_all": 13,     # ppc-3 page kernel: every page loads its static chunks
     "obs_chunk_mb": 14,      # pw_obs_alloc: MiB per physical chunk (0 = default, 32)
     "obs_accept_gbs": 15,    # pw_obs_alloc_tuned: rate at which a candidate buffer is kept right away
-    "step_tables": 16,       # overlap tables: 0 / "auto" (all puzzles if any has a movable beyond 8 x 8), 1 / "all", 2 / "none", 3 / "big"
+    "step_tables": 16,       # overlap tables: 0 / "auto" = 1 / "all" (every puzzle), 2 / "none", 3 / "big" (movables beyond 8 x 8 only)
     "step_table_bytes": 17,    # read-only
     "step_table_puzzles": 18,  # read-only
     "step_narrow_groups": 19,  # N_pad 16: 8-lane groups with two movables per lane

@@ -57,11 +57,11 @@ def _step_options(kernel):
         return {"step_kernel": "group", "step_lds_tables": 1, "step_tables": "big"}
     if kernel == "group-notables":
         return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "none"}
-    if kernel == "group-lds":
-        return {"step_kernel": "group", "step_lds_tables": 1}
+    if kernel == "group-lds":  # (the table-only kernels have nothing to stage: row loops, rows in LDS)
+        return {"step_kernel": "group", "step_lds_tables": 1, "step_tables": "none"}
     if kernel == "group-wide":  # N_pad 32 pools: 32 lanes per environment instead of two movables per lane
         return {"step_kernel": "group", "step_lds_tables": 2, "step_wide_groups": 1}
-    return {"step_kernel": kernel, "step_lds_tables": 2}
+    return {"step_kernel": kernel, "step_lds_tables": 2}  # "group": the defaults (tables for every puzzle)
 
 
 @pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
@@ -405,16 +405,22 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
                 assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-notables", "group-bigtables", "group-level1",
+                                    "group-narrow", "lane"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):
     """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's
     reward / terminated / truncated, on a mixed batch, with and without next-step autoreset; the
-    per-step history of the plan sequences also equals the golden rewards of the reference."""
+    per-step history of the plan sequences also equals the golden rewards of the reference.
+    "group-level1" / "group-narrow": the Level-1 pool (N_pad 16), where launches of several steps run in 8-lane groups
+    with two movables per lane (automatically with the table-only kernels; forced, also for the single steps)."""
     torch = torch_mod
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = [k for k in golden.keys if k.startswith(("bench:", "pytest:"))]
+    if kernel in ("group-level1", "group-narrow"):
+        keys = [k for k in golden.keys if k.startswith("bench:level1/")]
+        kernel = "group" if kernel == "group-level1" else kernel
     pool = [puzzles[k] for k in keys]
     envs = []
     for pi, k in enumerate(keys):

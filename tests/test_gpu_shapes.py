@@ -101,9 +101,10 @@ def test_random_shapes_expand4_matches_oracle(n_movables, seed):
 
 
 @pytest.mark.parametrize("n_movables,options", [(5, {}), (12, {}), (18, {}), (18, {"step_wide_groups": 1}),
-                                                (18, {"step_lds_tables": 1}), (5, {"step_tables": "all"}),
-                                                (12, {"step_tables": "none"}), (18, {"step_tables": "all"}),
-                                                (18, {"step_tables": "all", "step_lds_tables": 1})])
+                                                (18, {"step_lds_tables": 1, "step_tables": "none"}), (5, {"step_tables": "none"}),
+                                                (12, {"step_tables": "none"}), (18, {"step_tables": "none"}),
+                                                (12, {"step_tables": "big"}), (12, {"step_narrow_groups": 1}),
+                                                (12, {"step_narrow_groups": 1, "step_tables": "none"})])
 def test_random_shapes_step_matches_oracle(torch_mod, n_movables, options):
     """The same states through pw_step (8 / 16 lanes, two movables per lane, 32 lanes, LDS-staged rows)."""
     from oracle import c_oracle

@@ -372,7 +372,7 @@ def _sets_from_overlap_tables(words, d, parsed):
 def test_overlap_tables_are_the_reference_collision_tables(golden):
     """PW_OPT_STEP_TABLES: the sets read back out of the engine's overlap tables have the sizes and the
     SHA-256 (over sorted contents) the reference's own tables have -- every benchmark puzzle with a movable beyond
-    8 x 8 cells plus a sample of the others (mode 1: every puzzle; what a set with a big movable gets by default)."""
+    8 x 8 cells plus a sample of the others (mode 1 = the default: every puzzle)."""
     big = []
     for k in golden.keys:
         if k.startswith("bench:") and any(max(c[0] for c in cells) >= 8 or max(c[1] for c in cells) >= 8
@@ -388,11 +388,9 @@ def test_overlap_tables_are_the_reference_collision_tables(golden):
     assert pset.overlap_tables(2)[0].size == 1
     words, dirs = pset.overlap_tables(1)
     assert all(d[0] for d in dirs)
-    # automatic (the default): every puzzle as soon as one of the set has a big movable, otherwise none
+    # automatic (the default) = every puzzle
     wa, da = pset.overlap_tables(0)
     assert np.array_equal(wa, words) and np.array_equal(da, dirs)
-    only_small = _capi.PuzzleSet([p for k, p in zip(keys, parsed) if k not in big], -1)
-    assert only_small.overlap_tables(0)[0].size == 1 and not only_small.overlap_tables(0)[1][:, 0].any()
     for k, p, d, d0 in zip(keys, parsed, dirs, dir0):
         if d0[0]:  # same tables whichever mode built them
             n_words = p.num_movables ** 2 * (int(d[2]) & 0xffff) + p.num_movables * (int(d[2]) >> 16)
