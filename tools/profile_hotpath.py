@@ -29,7 +29,7 @@ def main():
     B = args.envs
     if args.config == "c4":  # rank 0's shard of the 8-rank assignment, exactly as bench.py --config c4 builds it
         wl = argparse.Namespace(envs_per_gpu=B, obs=args.obs, config="c4", max_steps=200, bw=args.bw, ppc=args.ppc,
-                                tune_allocations=1)
+                                tune_allocations=None)
         vec = bench.build_workload(wl, 0, 8, 0)["vec"]
     else:
         paths = bench.level1_paths()
