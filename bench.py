@@ -496,8 +496,9 @@ def main():
                 from make_pmc_record import kernel_source_sha
                 if rec.get("envs") == B and rec.get("obs_bytes") == eng.obs_bytes and \
                         rec.get("kernel") == eng.render_kernel and not args.fused:
-                    if rec.get("kernel_source_sha16") == kernel_source_sha():
-                        traffic = rec.get("hbm_bytes_per_launch")
+                    variant = rec.get("by_page_load_all", {}).get(str(eng.get_option("page_load_all")))
+                    if rec.get("kernel_source_sha16") == kernel_source_sha() and variant:
+                        traffic = variant.get("hbm_bytes_per_launch")
                         traffic_source = "recorded: profiles/pmc_render_latest.json (rocprofv3 --pmc passes of " \
                                          + str(rec.get("source", "an earlier run")) + ", head " + str(rec.get("git_head")) \
                                          + ", same kernel source), not measured in this run"

@@ -31,40 +31,46 @@ def git_head():
         return None
 
 
-def mean_counter(db, kernel, counter):
+def mean_counter(db, kernel, counter, load_all):
+    """Mean of `counter` over the dispatches of the page kernel's instances with / without kLoadAll (the production
+    symbol <T, 0, L> and the tuner's <T, 1, L> are the same code): (name of the most frequent symbol, mean, dispatches)."""
     con = sqlite3.connect(db)
     rows = con.execute(
         "select k.name, avg(p.counter_value), count(*) from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "
         "where p.counter_name = ? group by k.name", (counter,)).fetchall()
-    best = None
-    for name, val, n in rows:
-        # the production symbol only (kTag = 0), not the tuner's trial launches (kTag = 1)
-        if kernel in name and ", 1>" not in name and ", 1," not in name and (best is None or n > best[2]):
-            best = (name, val, n)
-    if best is None:
-        raise SystemExit(f"{counter}: no kernel matching {kernel!r} in {db}")
-    return best
+    want = ", true>" if load_all else ", false>"
+    sel = [(name, val, n) for name, val, n in rows if kernel in name and want in name]
+    if not sel:
+        return None
+    total = sum(n for _, _, n in sel)
+    return max(sel, key=lambda r: r[2])[0], sum(val * n for _, val, n in sel) / total, total
 
 
 def main():
     fetch_db, write_db, kernel, envs, obs_bytes, source = sys.argv[1:7]
-    fname, fetch_kb, fn = mean_counter(fetch_db, kernel, "FETCH_SIZE")
-    wname, write_kb, wn = mean_counter(write_db, kernel, "WRITE_SIZE")
+    variants = {}
+    for load_all in (0, 1):
+        f = mean_counter(fetch_db, kernel, "FETCH_SIZE", load_all)
+        w = mean_counter(write_db, kernel, "WRITE_SIZE", load_all)
+        if f is None or w is None:
+            continue
+        variants[str(load_all)] = {
+            "kernel_symbol": f[0], "hbm_bytes_per_launch": (2.0 * f[1] + w[1]) * 1024.0, "write_size_kb": w[1],
+            "fetch_size_kb_raw": f[1], "dispatches": [f[2], w[2]],
+        }
+    if not variants:
+        raise SystemExit(f"no kernel matching {kernel!r} in {fetch_db} / {write_db}")
     rec = {
         "kernel": kernel,
-        "kernel_symbol": fname,
         "envs": int(envs),
         "obs_bytes": int(obs_bytes),
-        "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
-        "write_size_kb": write_kb,
-        "fetch_size_kb_raw": fetch_kb,
-        "dispatches": [fn, wn],
+        "by_page_load_all": variants,  # the tuner picks the instance per buffer: bench.py reads the one it runs
         "source": source,
         "kernel_source_sha16": kernel_source_sha(),
         "git_head": git_head(),
-        "note": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, --kernel-trace only), mean over the "
-                "dispatches of the kernel on the C3 workload; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
-                "tallies 128-B requests as 64 B)",
+        "note": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, --kernel-trace only), mean over all "
+                "dispatches of the kernel's instances (production <T, 0, L> and the tuner's <T, 1, L>: same code) on the "
+                "C3 workload; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B)",
     }
     print(json.dumps(rec, indent=1))
 
