@@ -61,6 +61,28 @@ def git_head():
         return None
 
 
+def device_report(device_index):
+    """Name and clocks of the GPU the line was measured on (rocm-smi, best effort): what the render kernel reaches
+    differs from box to box, so the line says which box state it saw."""
+    rep = {}
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        rep["name"] = props.name
+        rep["total_memory_gb"] = round(props.total_memory / 2**30, 1)
+        rep["compute_units"] = props.multi_processor_count
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showperflevel", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        data = json.loads(txt[txt.index("{"):])
+        card = next(iter(data.values()))
+        rep["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("clock", "power", "performance"))}
+    except Exception:  # noqa: BLE001 -- no rocm-smi on the box, other output format
+        pass
+    return rep
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -425,6 +447,7 @@ def main():
         except OSError:
             pass
 
+    device_info = device_report(device_index)  # right after the timed windows: the clocks the GPU was left at
     n_obj = eng.np
     state_bytes = 2 * n_obj * 2 + 1 + 4 + 4 * 2 + 8 + 1 + 1 + 1  # pos r/w, action, pid, steps r/w, reward, flags
     out = {
@@ -461,7 +484,8 @@ def main():
             "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
                               "allocations_tried": len(vec.tuned_candidates_ms),
                               "allocations_max": args.tune_allocations if args.tune_allocations is not None else "product default (<= 4)",
-                              "allocator": "pw_obs_alloc_tuned (HIP virtual-memory chunks; losers released to the device)",
+                              "allocator": ("pw_obs_alloc_tuned (HIP virtual-memory chunks; losers released to the device)"
+                                            if getattr(vec, "obs_owned_by_library", False) else "torch (caller-owned buffer, tuned in place)"),
                               "torch_reserved_bytes": int(torch.cuda.memory_reserved(dev)),
                               "page_load_all": eng.get_option("page_load_all"),
                               "candidates_ms": [round(x, 4) for x in vec.tuned_candidates_ms],
@@ -469,6 +493,7 @@ def main():
                               "page_run_log2": eng.get_option("page_run_log2"),
                               "page_lds_pad_kb": eng.get_option("page_lds_pad_kb")},
         },
+        "device": device_info,
         "timing": {
             "windows": M,
             "steps_per_window": K,

@@ -118,6 +118,7 @@ class VecPushWorld:
         self.tuned_candidates_ms = []  # the same for every candidate allocation it tried (tune_allocations)
         self._has_reset = False
         self._obs_storage, self.obs = None, None
+        self.obs_owned_by_library = False
         if observation is not None:
             nbytes = self.num_envs * self.engine.obs_stride
             if tune is None:
@@ -127,13 +128,22 @@ class VecPushWorld:
                 # the library chooses among the candidates there are when memory runs out)
                 total = torch.cuda.get_device_properties(self.device).total_memory
                 tune_allocations = min(4, max(1, int(total // 4 // nbytes)))
+            owned = False
             if tune and tune_allocations:
                 # library-owned buffer: candidates are tuned on the initial states (reset() draws them again)
                 self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, None)
-                self._obs_storage, self.obs, self.tuned_config, self.tuned_candidates_ms = \
-                    self.engine.alloc_obs_tuned(self.puzzle_id, self.pos, int(tune_allocations))
-                self.tuned_ms = self.engine.get_option("tuned_ns") * 1e-6
-            else:
+                try:
+                    self._obs_storage, self.obs, self.tuned_config, self.tuned_candidates_ms = \
+                        self.engine.alloc_obs_tuned(self.puzzle_id, self.pos, int(tune_allocations))
+                    self.tuned_ms = self.engine.get_option("tuned_ns") * 1e-6
+                    owned = True
+                except (RuntimeError, MemoryError) as exc:
+                    # the HIP virtual-memory API refused (old runtime, exotic device): the same kernels on a torch buffer
+                    import warnings
+
+                    warnings.warn(f"pw_obs_alloc_tuned failed ({exc}); using a torch-owned observation buffer", RuntimeWarning)
+            self.obs_owned_by_library = owned
+            if not owned:
                 self._obs_storage, self.obs = self.engine.alloc_obs(self.num_envs)
                 if tune:
                     self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, None)
