@@ -270,3 +270,36 @@ def test_empty_batches_and_zero_steps_are_no_ops(torch_mod):
     assert _capi.lib.pw_expand4(eng.handle, 0, None, None, None, None, 0, None) == _capi.PW_OK
     assert _capi.lib.pw_expand4(eng.handle, 0, None, None, None, None, 5, None) == _capi.PW_EINVAL  # 5 states, no buffers
     assert _capi.lib.pw_step(None, None, None, None, None, None, None, None, None, 0, 0, None) == _capi.PW_EINVAL  # no engine
+
+
+def test_block_order_is_chosen_from_the_batch_and_never_changes_results(torch_mod):
+    """PW_OPT_STEP_BLOCK_ORDER: VecPushWorld starts the step kernel at the expensive END of a batch whose puzzles get
+    heavier (more movables) towards the end; an explicit engine option wins; the order never changes a result."""
+    torch = torch_mod
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    pool = sorted((PushWorldPuzzle(p) for p in bench.level1_paths()), key=lambda z: z.num_movables)
+    B = 8192
+    up = (np.arange(B, dtype=np.int64) * len(pool)) // B        # light puzzles first, heavy ones last
+    vecs = {
+        "auto-up": VecPushWorld(pool, B, puzzle_ids=up, max_steps=30, observation=None, device=0, autoreset=True),
+        "auto-down": VecPushWorld(pool, B, puzzle_ids=up[::-1].copy(), max_steps=30, observation=None, device=0, autoreset=True),
+        "forced": VecPushWorld(pool, B, puzzle_ids=up, max_steps=30, observation=None, device=0, autoreset=True,
+                               engine_options={"step_block_order": "forward"}),
+    }
+    assert vecs["auto-up"].engine.get_option("step_block_order") == 1
+    assert vecs["auto-down"].engine.get_option("step_block_order") == 0
+    assert vecs["forced"].engine.get_option("step_block_order") == 0
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    acts = torch.randint(0, 4, (40, B), generator=g, device="cuda:0", dtype=torch.uint8)
+    for v in vecs.values():
+        v.reset()
+    for t in range(40):
+        a, f = vecs["auto-up"].step(acts[t]), vecs["forced"].step(acts[t])
+        d = vecs["auto-down"].step(acts[t].flip(0))
+        assert torch.equal(vecs["auto-up"].pos, vecs["forced"].pos) and torch.equal(a[1], f[1]) and torch.equal(a[2], f[2])
+        assert torch.equal(vecs["auto-down"].pos.flip(0), vecs["forced"].pos) and torch.equal(d[1].flip(0), f[1])
+    ru, rf = vecs["auto-up"].rollout(acts), vecs["forced"].rollout(acts)
+    assert torch.equal(vecs["auto-up"].pos, vecs["forced"].pos) and torch.equal(ru[0], rf[0])

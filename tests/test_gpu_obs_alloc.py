@@ -149,3 +149,24 @@ def test_vec_env_binds_its_observation_once(torch_mod):
     alt.reset()
     alt.set_states(vec.states())
     assert torch.equal(alt.render(), obs0)
+
+
+def test_vec_env_falls_back_to_a_torch_buffer_when_the_allocator_refuses(torch_mod, monkeypatch):
+    """A runtime without the virtual-memory API: the same kernels on a torch-owned buffer, with a warning."""
+    torch = torch_mod
+    from pushworld_amd import _capi
+
+    def refuse(self, puzzle_id, pos, max_candidates):
+        raise RuntimeError("pw_obs_alloc: hipMemCreate: operation not supported")
+
+    monkeypatch.setattr(_capi.Engine, "alloc_obs_tuned", refuse)
+    with pytest.warns(RuntimeWarning, match="torch-owned"):
+        vec, texts, ids = _level1(4096, tune=True, tune_allocations=2)
+    assert not vec.obs_owned_by_library and vec.tuned_config is not None and len(vec.tuned_candidates_ms) == 1
+    vec.reset()
+    g = torch.Generator(device=vec.device).manual_seed(5)
+    for _ in range(5):
+        vec.step(torch.randint(0, 4, (vec.num_envs,), generator=g, device=vec.device, dtype=torch.uint8))
+    envs = [0, 2048, 4095]
+    want = _oracle_obs(texts, ids, vec.states(), envs, vec.obs.shape[1] // 3, vec.obs.shape[2] // 3)
+    assert np.array_equal(vec.obs[envs].cpu().numpy(), want)
