@@ -288,9 +288,10 @@ int pw_obs_free(PwEngine* e, void* obs);
  * PW_STEP_AUTORESET step, where the reference raises ValueError, gym_env.py:195-196). */
 int64_t pw_engine_bad_actions(PwEngine* e, void* stream);
 
-/* Debug check of the preconditions the kernels do not test (they index with these values):
- * puzzle_id[i] inside the set; with `pos` != NULL also every movable inside its puzzle's grid
- * (0 <= x <= W - w, 0 <= y <= H - h) and zero padding beyond the puzzle's movables.
+/* Debug check of the preconditions of the step / render entry points: puzzle_id[i] inside the set; with `pos` != NULL
+ * also every movable inside its puzzle's grid (0 <= x <= W - w, 0 <= y <= H - h) and zero padding beyond the puzzle's
+ * movables.  The kernels are memory-safe without it -- a puzzle id outside the set is clamped into it, positions are
+ * range-checked wherever they index a row or a table -- but then compute the step of a puzzle / state nobody meant.
  * Synchronises `stream`.  Returns the number of offending environments (0 = fine; the lowest
  * offending index goes to *first_bad when given) or a negative error. */
 int64_t pw_validate_state(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, int32_t batch,

@@ -303,3 +303,47 @@ def test_block_order_is_chosen_from_the_batch_and_never_changes_results(torch_mo
         assert torch.equal(vecs["auto-down"].pos.flip(0), vecs["forced"].pos) and torch.equal(d[1].flip(0), f[1])
     ru, rf = vecs["auto-up"].rollout(acts), vecs["forced"].rollout(acts)
     assert torch.equal(vecs["auto-up"].pos, vecs["forced"].pos) and torch.equal(ru[0], rf[0])
+
+
+def test_garbage_ids_and_positions_are_memory_safe(torch_mod):
+    """A third-party C caller that hands over puzzle ids outside the set or positions outside the grid gets a
+    meaningless step, not a fault: ids are clamped into the set, positions are range-checked wherever they index.
+    Every step / render entry point, every step kernel; the device is still healthy afterwards and a clean batch of
+    the same engine is still bit-exact."""
+    torch = torch_mod
+    vec = _level1_vec(B=4096)
+    ref = _level1_vec(B=4096)
+    o_ref = ref.reset().clone()
+    vec.reset()
+    g = torch.Generator(device=vec.device).manual_seed(21)
+    bad_ids = torch.randint(-2**31, 2**31 - 1, (vec.num_envs,), generator=g, device=vec.device, dtype=torch.int64).to(torch.int32)
+    bad_pos = torch.randint(-128, 128, tuple(vec.pos.shape), generator=g, device=vec.device, dtype=torch.int16).to(torch.int8)
+    good_ids = vec.puzzle_id.clone()
+    eng = vec.engine
+    with pytest.raises(ValueError):
+        eng.validate(bad_ids, vec.pos)
+    for kernel in ("group", "wave", "lane"):
+        eng.set_option("step_kernel", kernel)
+        for tables in ("all", "none", "big"):
+            eng.set_option("step_tables", tables)
+            for ids, pos in ((bad_ids, vec.pos.clone()), (good_ids, bad_pos.clone()), (bad_ids, bad_pos.clone())):
+                a = torch.randint(0, 4, (vec.num_envs,), generator=g, device=vec.device, dtype=torch.uint8)
+                eng.step(ids, a, pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated, vec.flags)
+                eng.step_render(ids, a, pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
+                                vec._obs_storage, vec.flags)
+                eng.render(ids, pos, vec._obs_storage)
+                eng.step_render_delta(ids, a, pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated,
+                                      vec._obs_storage, vec.flags)
+                acts = torch.randint(0, 4, (8, vec.num_envs), generator=g, device=vec.device, dtype=torch.uint8)
+                eng.rollout(ids, acts, pos, vec.steps, vec.reward, vec.dgoals, vec.terminated, vec.truncated, flags=vec.flags)
+                eng.reset(ids, pos, vec.steps, vec.terminated, vec.truncated)
+            torch.cuda.synchronize()
+    eng.set_option("step_kernel", "group")
+    eng.set_option("step_tables", "auto")
+    # the engine and the device are fine: a clean episode equals the untouched twin
+    assert torch.equal(vec.reset(), o_ref)
+    for t in range(10):
+        a = torch.randint(0, 4, (vec.num_envs,), generator=g, device=vec.device, dtype=torch.uint8)
+        o1, r1, _, _ = vec.step(a)
+        o2, r2, _, _ = ref.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(vec.pos, ref.pos)
