@@ -229,7 +229,7 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       the frame padding (a more even write front; a candidate of pw_engine_tune_render) */
 #define PW_OPT_OBS_CHUNK_MB 14       /* pw_obs_alloc: MiB per physical chunk (0 = default, 32 MiB) */
 #define PW_OPT_OBS_ACCEPT_GBS 15     /* pw_obs_alloc_tuned: a candidate on which the tuned render reaches this many GB/s is
-                                      kept without looking further (default 6880 = 0.86 of the 8 TB/s peak) */
+                                      kept without looking further (default 7050 = 0.88 of the 8 TB/s peak) */
 #define PW_OPT_STEP_TABLES 16         /* overlap tables for the lane-group step / expansion / search kernels (the reference's
                                       collision tables, puzzle.py:259-311, with the four actions sharing one table; one or two
                                       8-byte loads instead of a loop over object rows): 0 (default) and 1 every puzzle that fits
