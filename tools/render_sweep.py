@@ -28,7 +28,13 @@ def main():
                            engine_options=opts)
         vec.reset()
         torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+        if "--settle" in sys.argv:  # memory the allocator just gave back may still be being cleared by the driver
+            import time
+            time.sleep(1.0)
+            for _ in range(20):
+                vec.render()
+            torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(24 if "--settle" in sys.argv else 8)]
         for a, b in evs:
             a.record()
             vec.render()
