@@ -101,7 +101,8 @@ def test_tuned_allocation_tries_candidates_and_releases_the_losers(torch_mod, ch
     assert torch.cuda.memory_reserved() == reserved0  # neither the winner nor the losers are torch's
     assert 1 <= len(cand) <= 3 and all(c > 0 for c in cand) and 0 <= idx < 20
     assert torch.equal(view, ref)
-    assert eng.get_option("tuned_ns") == pytest.approx(min(cand) * 1e6, rel=1e-3)
+    # candidates are screened (a few launches each); the full tuner then runs on the kept one
+    assert eng.get_option("tuned_ns") == pytest.approx(min(cand) * 1e6, rel=0.25)
     assert len(cand) >= 2  # 4 096 environments never reach the accept rate: at least two candidates were tuned
     # stepping into the owned buffer
     g = torch.Generator(device=vec.device).manual_seed(11)
