@@ -389,9 +389,8 @@ int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ
  * pw_expand4 semantics for the successors, an open-addressing visited table in HBM, and the new
  * states appended to a store with (parent, action) links.  State numbering is deterministic and
  * equals the one of a sequential FIFO search trying the actions in the order 0..3 (state 0 = start).
- * All device memory is allocated by pw_search_create: about max_states * (2N + 8) bytes for the store plus the visited
- * table -- 32 .. 64 bytes per state for puzzles of up to 6 movables, 64 .. 128 up to 14 (slots that hold the state itself: a
- * duplicate test is one random access), 16 .. 32 beyond (fingerprinted 8-byte slots) -- plus scratch. */
+ * All device memory is allocated by pw_search_create (about max_states * (2N + 40) bytes + scratch: the
+ * visited table is 16 .. 32 bytes per state -- 8-byte slots of (fingerprint, entry) at a load factor below one half). */
 /* Novelty tables: NoveltyHeuristic::estimate_cost_to_goal (cpp/src/heuristics/novelty.cc:30-77) for a
  * whole array of states.  novelty[k] is what the reference returns for state k when the states are fed
  * to it one after the other in index order, this call after all earlier calls: 1 = a moved object is at
