@@ -73,6 +73,40 @@ def classes(config, chunk_mb, n):
     print(config, "chunk_mb", chunk_mb, "tuned ms, index:", rows, flush=True)
 
 
+def soak(n):
+    """n constructions / destructions of the C3 environment in ONE process: candidates come and go, the free device memory
+    (hipMemGetInfo through the runtime torch loaded) must return to where it was, nothing may fault."""
+    import ctypes
+    import gc
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_mb():
+        fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
+        hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot))
+        return fr.value >> 20
+
+    base = None
+    for i in range(n):
+        wl, dt = workload("c3", None, 0)
+        vec = wl["vec"]
+        vec.reset()
+        acts = torch.randint(0, 4, (4, vec.num_envs), device=vec.device, dtype=torch.uint8)
+        for t in range(4):
+            vec.step(acts[t])
+        torch.cuda.synchronize()
+        row = (round(vec.tuned_ms, 4), len(vec.tuned_candidates_ms), round(dt, 2), free_mb())
+        del vec, wl, acts
+        gc.collect()
+        torch.cuda.synchronize()
+        after = free_mb()
+        if base is None:
+            base = after
+        print("cycle %2d: tuned %.4f ms, %d candidates, ctor %.2f s, free while alive %d MB, after %d MB (first cycle: %d)"
+              % (i, row[0], row[1], row[2], row[3], after, base), flush=True)
+    print("soak ok" if abs(after - base) < 512 else "LEAK: %d MB" % (base - after))
+
+
 def wrap():
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.vec_env import VecPushWorld
@@ -129,6 +163,8 @@ if __name__ == "__main__":
                 subprocess.run([sys.executable, os.path.abspath(__file__), "one", cfg] + rest, timeout=200)
             except subprocess.TimeoutExpired:
                 print("TIMEOUT", flush=True)
+    elif mode == "soak":
+        soak(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
     elif mode == "classes":
         cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
         classes(cfg, int(sys.argv[3]) if len(sys.argv) > 3 else 0, int(sys.argv[4]) if len(sys.argv) > 4 else 8)
