@@ -222,8 +222,9 @@ def test_full_small_images(golden, puzzles, torch_mod):
         assert (img == want).all(), (key, np.argwhere(img != want)[:5])
 
 
+# (page order, log2 run, KiB of LDS padding[, every page loads])
 PAGE_CONFIGS = [None, (0, 0, 0), (1, 0, 0), (1, 0, 5), (1, 1, 3), (1, 2, 0), (1, 3, 1), (2, 0, 0), (2, 3, 7), (2, 6, 0),
-                (2, 11, 2), (2, 20, 9)]
+                (2, 11, 2), (2, 20, 9), (0, 0, 0, 1), (1, 1, 7, 1), (2, 6, 7, 1)]
 
 
 @pytest.mark.parametrize("obs_kind", ["uint8", "float32"])
@@ -248,7 +249,7 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     # every launch configuration of the page kernel (page order, run length, occupancy padding; None = defaults)
     # and both producers of its page records: the step kernel (fused=True -> pw_step_render) and the pre-pass
     ref = make({"render_kernel": "lds"})
-    alt = make({} if path is None else dict(zip(("page_order", "page_run_log2", "page_lds_pad_kb"), path)))
+    alt = make({} if path is None else dict(zip(("page_order", "page_run_log2", "page_lds_pad_kb", "page_load_all"), path)))
     alt.fused = path is None or path[0] != 1
     assert ref.engine.render_kernel != "pw_render_page_kernel" and alt.engine.render_kernel == "pw_render_page_kernel"
     o_ref, o_alt = ref.reset(), alt.reset()
