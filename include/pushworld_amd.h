@@ -245,6 +245,12 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_STEP_BLOCK_ORDER 20   /* lane-group step kernels: 0 workgroups take the environments in index order, 1 in reverse --
                                       for batches sorted by puzzle whose expensive puzzles (many / big movables) come last:
                                       they then start first and the cheap ones fill the tail of the launch */
+#define PW_OPT_STEP_LANE_BATCH 21    /* state-only launches (pw_step, pw_rollout) of at least this many environments run ONE LANE per
+                                      environment (the table-only formulation, 64 environments per wavefront: ~3x fewer
+                                      instructions per environment than a lane group, but an eighth of the wavefronts -- it wins
+                                      once the batch alone fills the chip; needs overlap tables for every puzzle of the set).
+                                      0 = default (131 072 for sets with up to 16 movables per puzzle; N_pad 32 sets: 196 608 for
+                                      one step per launch, 393 216 for pw_rollout); a threshold no batch reaches (2^31) = never */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

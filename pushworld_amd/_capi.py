@@ -172,9 +172,10 @@ OPTIONS = {
     "step_table_puzzles": 18,  # read-only
     "step_narrow_groups": 19,  # N_pad 16: 8-lane groups with two movables per lane
     "step_block_order": 20,    # 0 / "forward", 1 / "reverse": which end of the batch the step kernel starts with
+    "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2,
-                  "forward": 0, "reverse": 1}
+                  "forward": 0, "reverse": 1, "never": 2**31}
 
 
 def _load():

@@ -305,6 +305,34 @@ def test_block_order_is_chosen_from_the_batch_and_never_changes_results(torch_mo
     assert torch.equal(vecs["auto-up"].pos, vecs["forced"].pos) and torch.equal(ru[0], rf[0])
 
 
+def test_big_state_only_batches_run_one_lane_per_environment(torch_mod):
+    """PW_OPT_STEP_LANE_BATCH: a state-only launch of >= 131 072 environments (N_pad <= 16 sets) runs the one-lane-per-
+    environment formulation by itself; same results as the lane groups (option "never"), step by step and as a rollout."""
+    torch = torch_mod
+    import bench
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    pool = [PushWorldPuzzle(p) for p in bench.level1_paths()]
+    B = 196608
+    ids = (np.arange(B, dtype=np.int64) * len(pool)) // B
+    auto = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=25, observation=None, device=0, autoreset=True)
+    groups = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=25, observation=None, device=0, autoreset=True,
+                          engine_options={"step_lane_batch": "never"})
+    assert auto.engine.get_option("step_lane_batch") == 131072 and groups.engine.get_option("step_lane_batch") == 2**31
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    acts = torch.randint(0, 4, (48, B), generator=g, device="cuda:0", dtype=torch.uint8)
+    auto.reset()
+    groups.reset()
+    for t in range(32):
+        a, b = auto.step(acts[t]), groups.step(acts[t])
+        assert torch.equal(auto.pos, groups.pos) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        assert torch.equal(auto.steps, groups.steps)
+    ra, rb = auto.rollout(acts), groups.rollout(acts)
+    assert torch.equal(auto.pos, groups.pos) and all(torch.equal(x, y) for x, y in zip(ra, rb))
+    assert int(auto.terminated.sum()) == int(groups.terminated.sum())
+
+
 def test_garbage_ids_and_positions_are_memory_safe(torch_mod):
     """A third-party C caller that hands over puzzle ids outside the set or positions outside the grid gets a
     meaningless step, not a fault: ids are clamped into the set, positions are range-checked wherever they index.

@@ -13,10 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-extras"]
 
 
-def run_bench(*argv, timeout=600):
+def run_bench(*argv, timeout=600, extra_env=None):
     env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST"):
         env.pop(k, None)
+    env.update(extra_env or {})
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
                           timeout=timeout, env=env, cwd=ROOT)
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
@@ -61,6 +62,26 @@ def test_self_spawned_two_ranks_sum_their_counters():
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["one_thread"]["cores"] == 1 and cb["cpu_model"]
     assert cb["python_env"]["value"] > 0 and cb["python_env"]["processes"]["cores"] >= 1
+
+
+def test_rccl_branch_runs_with_one_rank():
+    """The N > 1 plumbing over RCCL on the one device a test box has: BENCH_FORCE_DIST=1 makes a single rank take the
+    collective path -- init_process_group("nccl", device_id=...), the probe all_reduce, barriers, the SUM / MAX
+    reductions and the per-rank gathers on device tensors -- so that the first 8-GPU run is not the first time that code
+    executes."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    proc, lines = run_bench(*SMALL, "--no-cpu-baseline", timeout=600,
+                            extra_env={"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 1 and "counters over nccl" in d["config"]["parallelism"]
+    assert d["config"]["global_batch"] == 2048 and abs(d["value"] - 2048 * 3 / (d["ms_per_step"] * 3 / 1000.0)) < 1e-6 * d["value"]
+    assert len(d["roofline"]["per_rank_frac"]) == 1 and len(d["timing"]["per_rank_median_ms_per_step"]) == 1
 
 
 def test_more_ranks_than_devices_is_refused():

@@ -61,7 +61,12 @@ def _step_options(kernel):
         return {"step_kernel": "group", "step_lds_tables": 1, "step_tables": "none"}
     if kernel == "group-wide":  # N_pad 32 pools: 32 lanes per environment instead of two movables per lane
         return {"step_kernel": "group", "step_lds_tables": 2, "step_wide_groups": 1}
-    return {"step_kernel": kernel, "step_lds_tables": 2}  # "group": the defaults (tables for every puzzle)
+    if kernel == "big-batch":  # what state-only launches of >= 131 072 environments pick by themselves (PW_OPT_STEP_LANE_BATCH)
+        return {"step_kernel": "group", "step_lds_tables": 2, "step_lane_batch": 1}
+    if kernel == "lane-notables":  # one lane per environment with the row loops (the engine has no tables)
+        return {"step_kernel": "lane", "step_lds_tables": 2, "step_tables": "none"}
+    # "group", "lane": the defaults (tables for every puzzle: the loop-free instances); "wave": rows only
+    return {"step_kernel": kernel, "step_lds_tables": 2}
 
 
 @pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
@@ -71,7 +76,10 @@ def _step_options(kernel):
                                           ("bench", "group-notables"), ("tests", "group-notables"),
                                           ("bench", "group-bigtables"), ("bench", "group-bigtables-lds"),
                                           ("level1", "group"), ("level1", "group-narrow"), ("level1", "group-lds"),
-                                          ("bench", "lane"), ("tests", "lane"), ("bench", "wave"), ("tests", "wave")])
+                                          ("bench", "lane"), ("tests", "lane"), ("l0", "lane"), ("level1", "lane"),
+                                          ("bench", "lane-notables"), ("tests", "lane-notables"),
+                                          ("bench", "big-batch"), ("l0", "big-batch"),
+                                          ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
     one mixed batch: positions, float64 reward bits, terminated, truncated, step counter.
@@ -129,7 +137,8 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-tables", "group-notables", "group-bigtables", "lane", "wave"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-tables", "group-notables", "group-bigtables", "lane",
+                                    "lane-notables", "wave"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
@@ -407,7 +416,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
 
 
 @pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-notables", "group-bigtables", "group-level1",
-                                    "group-narrow", "lane"])
+                                    "group-narrow", "lane", "lane-notables", "big-batch"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):
     """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's

@@ -48,8 +48,7 @@ def is_big(parsed):
     return any(max(c[0] for c in cells) >= 8 or max(c[1] for c in cells) >= 8 for cells in parsed.object_cells)
 
 
-def workloads(which):
-    B = 65536
+def workloads(which, B=65536):
     if "c2" in which:
         l0 = bd.load_level0(("base",), "train", 1)
         yield "C2 4096 x one L0 puzzle", l0, 4096, np.zeros(4096, np.int64)
@@ -57,6 +56,9 @@ def workloads(which):
         from pushworld_amd.puzzle import PushWorldPuzzle
         paths = bench.level1_paths()
         yield "C3 65536 Level-1", [PushWorldPuzzle(p) for p in paths], B, (np.arange(B, dtype=np.int64) * len(paths)) // B
+    if "l0" in which:
+        l0 = [_capi.ParsedPuzzle(t) for t in bd.level0_texts(("all",), "train", 2000).values()]
+        yield "65536 over 2000 L0 'all'", _capi.PuzzleSet(l0, 0), B, (np.arange(B, dtype=np.int64) * len(l0)) // B
     hi = level_texts((1, 2, 3, 4))
     if "c4" in which:
         texts = list(bd.level0_texts().values())
@@ -84,15 +86,20 @@ def main():
     ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--which", default="c2,c3,c4,l14,nobig,gap")
     ap.add_argument("--modes", default="none+fwd,auto+fwd,auto,all+fwd,all,all+narrow")
+    ap.add_argument("--batch", type=int, default=65536, help="environments of every workload but C2")
     args = ap.parse_args()
     print("%-30s %-12s %9s %9s %13s %15s %10s" % ("workload", "tables", "step med", "step min", "rollout64 us", "rollout steps/s", "table KB"))
-    for name, pool, B, ids in workloads(args.which.split(",")):
+    for name, pool, B, ids in workloads(args.which.split(","), args.batch):
         for mode in args.modes.split(","):
             opts = {"step_tables": mode.split("+")[0]}
             if "+narrow" in mode:
                 opts["step_narrow_groups"] = 1
             if "+fwd" in mode:   # (VecPushWorld picks the reverse order by itself when the expensive puzzles come last)
                 opts["step_block_order"] = "forward"
+            if "+lane" in mode and "+nolane" not in mode:  # one lane per environment (table-driven when every puzzle has tables)
+                opts["step_kernel"] = "lane"
+            if "+nolane" in mode:  # lane groups whatever the batch size
+                opts["step_lane_batch"] = "never"
             if "+rev" in mode:
                 opts["step_block_order"] = "reverse"
             vec = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=200, observation=None, autoreset=True, engine_options=opts)
