@@ -54,6 +54,19 @@ struct PwOvlDir {
   uint32_t reserved;
 };
 
+// Push tables of one puzzle (engine-built from the overlap tables, sets of at most 64 puzzles: the planner's engines): the
+// reference's collision tables themselves (puzzle.py:259-311), the four actions interleaved as one NIBBLE per relative
+// offset -- bit a = "overlaps after action a and not now" -- so that one 4-byte load answers a push (or wall) test for all
+// four actions (pw_expand4_lane_kernel).  32-bit words, 8 nibbles each, addressed from PwEngine::d_ovl.
+//   pair table (i, j), R2 = 2 max_h + 1 rows of RW words:  nibble (rx + w_i) of row (ry + h_i), i at (rx, ry) relative to j
+//   wall table j, Hs = H + 2 rows of WW words:             nibble (x + 1) of row (y + 1)
+struct PwPushDir {
+  uint32_t pair_off;  // offset of pair table (0, 0) in 8-byte units from d_ovl; 0 = this puzzle has no push tables
+  uint32_t wall_off;
+  uint16_t R2, RW;
+  uint16_t Hs, WW;
+};
+
 // An observation buffer owned by the library (pw_obs_alloc): one reserved address range backed by physical chunks
 // created and mapped with the HIP virtual-memory API.  Unmapped, released and its address range freed by pw_obs_free /
 // pw_engine_destroy: the memory goes back to the DEVICE, not to a caching allocator.
@@ -101,6 +114,8 @@ struct PwEngine {
                            // 1 every puzzle, 2 none
   uint64_t* d_ovl;         // overlap tables of all puzzles that have them (word 0 unused)
   PwOvlDir* d_ovl_dir;     // [set size]
+  PwPushDir* d_push_dir;   // [set size], or NULL (sets of more than 64 puzzles carry no push tables)
+  std::vector<uint8_t> push_has;  // [set size] host copy: puzzle p has push tables
   int64_t ovl_bytes;
   int ovl_puzzles;         // puzzles with tables
   std::vector<uint8_t> ovl_has;  // [set size] host copy: puzzle p has tables

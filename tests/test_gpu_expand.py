@@ -56,6 +56,14 @@ def bfs(puzzle, max_states):
     "cpptest:necessary_transitive_pushing3.pwp|all",
     # 9 .. 16 movables: 8-lane groups with two movables per lane by default; "wide": one movable per lane, 16 lanes
     "bench:level4/Four Pistons.pwp|wide", "bench:level4/Mind The Gap.pwp|wide", "bench:level1/Pulling.pwp|wide",
+    # one lane per state (pw_expand4_lane_kernel: what frontiers of >= 131 072 states run by themselves), forced here
+    # for layers of every size incl. ragged last blocks
+    "cpptest:trivial.pwp|lanes", "cpptest:trivial_tool2.pwp|lanes", "cpptest:blocked_transitive_pushing1.pwp|lanes",
+    "cpptest:blocked_transitive_pushing2.pwp|lanes", "cpptest:necessary_transitive_pushing3.pwp|lanes",
+    "cpptest:multiple_goals.pwp|lanes", "cpptest:file_parsing.pwp|lanes", "bench:level1/2 Obstacle.pwp|lanes",
+    "bench:level2/Pull Dont Push.pwp|lanes", "bench:level4/Four Pistons.pwp|lanes", "bench:level4/Mind The Gap.pwp|lanes",
+    "bench:level3/Armor.pwp|lanes", "bench:level3/Rocky Shore.pwp|lanes", "bench:level2/Bubbles.pwp|lanes",
+    "bench:level3/Moving Mountains.pwp|lanes",
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle
@@ -68,6 +76,8 @@ def test_bfs_layers_match_oracle(golden, key):
     pz = PushWorldPuzzle(text=text, order="cpp")
     if tables == "wide":
         pz._engine().set_option("step_wide_groups", 1)
+    elif tables == "lanes":
+        pz._engine().set_option("step_kernel", "lane")
     elif tables:
         pz._engine().set_option("step_tables", tables)
         assert (pz._engine().get_option("step_table_puzzles") == 1) == (tables == "all")

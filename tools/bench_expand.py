@@ -28,17 +28,28 @@ def frontier(pz, target):
 
 
 def main():
-    cases = [(rel, 200000, mode) for rel in ("level1/2 Obstacle.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp")
-             for mode in ("auto", "all")]
-    cases += [("level4/Mind The Gap.pwp", 200000, "none"), ("level4/Mind The Gap.pwp", 200000, "auto")]
-    for rel, target, mode in cases:
+    # kernels: "groups" = one lane group per state whatever the frontier size (PW_OPT_STEP_LANE_BATCH never), "auto" = the
+    # default (one lane per state from 131 072 states on, puzzles with tables and <= 16 movables), "lanes" = always
+    sizes = [int(x) for x in sys.argv[sys.argv.index("--sizes") + 1].split(",")] if "--sizes" in sys.argv else [1_000_000]
+    cases = [(rel, 200000, "auto", k, F) for rel in ("level1/2 Obstacle.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp")
+             for F in sizes for k in ("groups", "auto")]
+    cases += [("level4/Mind The Gap.pwp", 200000, "none", "auto", sizes[-1]), ("level4/Mind The Gap.pwp", 200000, "auto", "groups", sizes[-1]),
+              ("level4/Mind The Gap.pwp", 200000, "auto", "auto", sizes[-1])]
+    fronts = {}
+    for rel, target, mode, kernel, size in cases:
         pz = PushWorldPuzzle(os.path.join(BENCHMARK_PUZZLES_PATH, rel), order="cpp")
         pz._engine().set_option("step_tables", mode)  # PW_OPT_STEP_TABLES
-        rel = "%s [tables %s]" % (rel, mode)
+        if kernel == "groups":
+            pz._engine().set_option("step_lane_batch", "never")
+        elif kernel == "lanes":
+            pz._engine().set_option("step_kernel", "lane")
         t0 = time.time()
-        st = frontier(pz, target)
-        reps = max(1, 1_000_000 // len(st))
-        states = torch.as_tensor(np.tile(st, (reps, 1))).to("cuda:0")
+        if rel not in fronts:
+            fronts[rel] = frontier(pz, target)
+        st = fronts[rel]
+        rel = "%s [tables %s, %s]" % (rel, mode, kernel)
+        reps = max(1, -(-size // len(st)))
+        states = torch.as_tensor(np.tile(st, (reps, 1))[:max(size, 1)]).to("cuda:0")
         F, N = states.shape
         eng = pz._engine()
         succ = torch.empty((F, 4, N), dtype=torch.int32, device="cuda:0")
@@ -48,13 +59,13 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(10):
             eng.expand4(0, states, succ, moved, goal)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        ms = e0.elapsed_time(e1) / 10
         algo = F * (20 * N + 20)
-        print(f"{rel:44s} N={N:2d} distinct={len(st):7d} F={F:8d}  {ms:7.3f} ms  {F / ms * 1e3:11.3e} parents/s  "
+        print(f"{rel:52s} N={N:2d} distinct={len(st):7d} F={F:8d}  {ms:7.3f} ms  {F / ms * 1e3:11.3e} parents/s  "
               f"{4 * F / ms * 1e3:11.3e} successors/s  {algo / ms / 1e6:7.1f} GB/s algorithmic  (frontier build {time.time() - t0:.1f}s)",
               flush=True)
 
