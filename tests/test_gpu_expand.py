@@ -97,6 +97,47 @@ def test_bfs_layers_match_oracle(golden, key):
             assert bool(goal[i, a]) == oz.py.is_goal_state(nxt), (key, i, a)
 
 
+@pytest.mark.parametrize("key", ["bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp", "bench:level4/Four Pistons.pwp",
+                                 "bench:level4/Mind The Gap.pwp", "bench:level1/Pulling.pwp"])
+def test_lane_kernel_with_unaligned_buffers_and_ragged_sizes(golden, key):
+    """pw_expand4_lane_kernel picks its store width (16 / 8 / 4 bytes) and how many actions it stages at a time from N
+    and from the alignment of the caller's buffers: output buffers that start 4 bytes (succ, moved) / 1 byte (goal) into
+    an allocation, and state counts around the 64-state blocks, give the same successors as the lane groups."""
+    import torch
+
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    if key not in golden.meta:
+        pytest.skip("puzzle not in the fixture set")
+    pz = PushWorldPuzzle(text=golden.text(key), order="cpp")
+    order, _, _, _, n = bfs(pz, 3000)
+    states = np.array(order[:n], dtype=np.int32)
+    N = states.shape[1]
+    eng = pz._engine()
+    dev = "cuda:0"
+    for F in (1, 63, 64, 65, 129, min(n, 1500)):
+        F = min(F, n)
+        st = torch.as_tensor(states[:F]).to(dev)
+        eng.set_option("step_kernel", "group")
+        eng.set_option("step_lane_batch", "never")
+        want = [torch.empty((F, 4, N), dtype=torch.int32, device=dev), torch.empty((F, 4), dtype=torch.int32, device=dev),
+                torch.empty((F, 4), dtype=torch.uint8, device=dev)]
+        eng.expand4(0, st, *want)
+        eng.set_option("step_kernel", "lane")
+        for off in (0, 1, 2):
+            raw = [torch.full((F * 4 * N + 8,), -7, dtype=torch.int32, device=dev), torch.full((F * 4 + 8,), -7, dtype=torch.int32, device=dev),
+                   torch.full((F * 4 + 8,), 77, dtype=torch.uint8, device=dev)]
+            got = [raw[0][off:off + F * 4 * N].view(F, 4, N), raw[1][off:off + F * 4].view(F, 4), raw[2][off:off + F * 4].view(F, 4)]
+            eng.expand4(0, st, *got)
+            torch.cuda.synchronize()
+            for g, w in zip(got, want):
+                assert torch.equal(g, w), (key, F, off)
+            # nothing outside the views was written
+            assert int((raw[0][:off] != -7).sum()) == 0 and int((raw[0][off + F * 4 * N:] != -7).sum()) == 0
+            assert int((raw[1][:off] != -7).sum()) == 0 and int((raw[1][off + F * 4:] != -7).sum()) == 0
+            assert int((raw[2][:off] != 77).sum()) == 0 and int((raw[2][off + F * 4:] != 77).sum()) == 0
+
+
 def test_cpp_known_answers():
     """cpp/test/test_pushworld_puzzle.cc:260-394 (trivial.pwp walk), cpp/test/search/
     test_best_first_search.cc:117 (no_solution.pwp has exactly 9 reachable states) and :122
