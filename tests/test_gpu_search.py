@@ -40,14 +40,19 @@ CASES = ["pytest:trivial.pwp", "pytest:trivial_obstacle.pwp", "pytest:trivial_to
          "l0:level0/all/train/level_0_all_train_3.pwp", "rand:3", "rand:17", "rand:42"]
 
 
-@pytest.mark.parametrize("chunk", [None, "7"])
+@pytest.mark.parametrize("chunk", [None, "7", "lanes", "mixed"])
 def test_bfs_numbering_equals_sequential_search(golden, chunk, monkeypatch):
     """Whole reachable space (capped at 60 000 states): every state, parent, action, layer boundary
-    and the first goal index equal the host FIFO search; chunk=7 forces many passes per layer."""
+    and the first goal index equal the host FIFO search; chunk=7 forces many passes per layer.  "lanes": the
+    one-lane-per-parent expansion kernel (what passes of >= 131 072 parents run by themselves) for every pass; "mixed":
+    lane groups and lanes alternating layer by layer (both must hash a state to the same slot)."""
     from oracle import c_oracle
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
 
+    lanes = chunk in ("lanes", "mixed")
+    mixed = chunk == "mixed"
+    chunk = None if lanes else chunk
     chunk_arg = int(chunk) if chunk else None
     cap = 3000 if chunk else 60000
     n_checked = 0
@@ -62,8 +67,12 @@ def test_bfs_numbering_equals_sequential_search(golden, chunk, monkeypatch):
         pz = PushWorldPuzzle(text=text)
         bfs = BreadthFirstSearch(pz, max_states=cap + 8, chunk=chunk_arg)
         bfs.begin()
+        layer = 0
         while not bfs.exhausted:
+            if lanes:
+                pz._engine().set_option("step_kernel", "group" if (mixed and layer % 2) else "lane")
             bfs.expand()
+            layer += 1
         assert bfs.total_states == len(want_states), key
         got = bfs.states()
         assert (got == np.array(want_states, dtype=np.int64).reshape(got.shape)).all(), key
@@ -269,14 +278,17 @@ def host_iw(oz, width, max_states=None):
 
 
 @pytest.mark.parametrize("width", [1, 2])
-@pytest.mark.parametrize("chunk", [None, "5"])
+@pytest.mark.parametrize("chunk", [None, "5", "lanes"])
 def test_width_limited_search_equals_host_model(golden, width, chunk, monkeypatch):
     """IW(1) / IW(2): states, links, pruned flags, layers and first goal equal the host model built from
-    the oracle step and the restated NoveltyHeuristic; with 5-parent passes as well."""
+    the oracle step and the restated NoveltyHeuristic; with 5-parent passes as well, and with the one-lane-per-parent
+    expansion kernel ("lanes")."""
     from oracle import c_oracle
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
 
+    lanes = chunk == "lanes"
+    chunk = None if lanes else chunk
     chunk_arg = int(chunk) if chunk else None
     keys = CASES + ["bench:level1/2 Obstacle.pwp", "bench:level1/Choose Wisely.pwp", "bench:level2/Pull Dont Push.pwp",
                     "cpptest:file_parsing.pwp", "bench:level2/Clean Sweep.pwp"]
@@ -291,6 +303,8 @@ def test_width_limited_search_equals_host_model(golden, width, chunk, monkeypatc
         if len(states) > cap:
             continue
         pz = PushWorldPuzzle(text=text)
+        if lanes:
+            pz._engine().set_option("step_kernel", "lane")
         bfs = BreadthFirstSearch(pz, max_states=cap + 8, novelty_width=width, chunk=chunk_arg)
         bfs.begin()
         while not bfs.exhausted:

@@ -41,6 +41,8 @@ def host_rate(text, seconds=3.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-states", type=int, default=40_000_000)
+    ap.add_argument("--groups", action="store_true", help="lane groups for every pass (PW_OPT_STEP_LANE_BATCH never) instead "
+                    "of one lane per parent from 131 072 parents on")
     args = ap.parse_args()
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
@@ -51,6 +53,8 @@ def main():
         with open(os.path.join(d, rel)) as f:
             text = f.read()
         pz = PushWorldPuzzle(text=text, order="cpp")
+        if args.groups:
+            pz._engine().set_option("step_lane_batch", "never")
         bfs = BreadthFirstSearch(pz, max_states=args.max_states)
         bfs.begin()
         bfs.expand()  # warm-up launch
