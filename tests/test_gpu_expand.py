@@ -63,7 +63,7 @@ def bfs(puzzle, max_states):
     "cpptest:multiple_goals.pwp|lanes", "cpptest:file_parsing.pwp|lanes", "bench:level1/2 Obstacle.pwp|lanes",
     "bench:level2/Pull Dont Push.pwp|lanes", "bench:level4/Four Pistons.pwp|lanes", "bench:level4/Mind The Gap.pwp|lanes",
     "bench:level3/Armor.pwp|lanes", "bench:level3/Rocky Shore.pwp|lanes", "bench:level2/Bubbles.pwp|lanes",
-    "bench:level3/Moving Mountains.pwp|lanes",
+    "bench:level3/Moving Mountains.pwp|lanes", "bench:level1/A Tight Squeeze.pwp|lanes",  # (N = 2: rows of one word)
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle
@@ -136,6 +136,25 @@ def test_lane_kernel_with_unaligned_buffers_and_ragged_sizes(golden, key):
             assert int((raw[0][:off] != -7).sum()) == 0 and int((raw[0][off + F * 4 * N:] != -7).sum()) == 0
             assert int((raw[1][:off] != -7).sum()) == 0 and int((raw[1][off + F * 4:] != -7).sum()) == 0
             assert int((raw[2][:off] != 77).sum()) == 0 and int((raw[2][off + F * 4:] != 77).sum()) == 0
+
+
+def test_lane_kernel_on_an_agent_alone():
+    """N = 1 (an agent, walls, nothing to push, no goal): rows of one Position2D, divisions by one in the staging code."""
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    text = "\n".join("  ".join(r) for r in ([".", "W", ".", "."], ["A", ".", ".", "W"], [".", ".", "AW", "."]))
+    pz = PushWorldPuzzle(text=text, order="cpp")
+    oz = c_oracle.COraclePuzzle(text, order="cpp")
+    pz._engine().set_option("step_kernel", "lane")
+    order, succ, moved, goal, n = bfs(pz, 1000)
+    assert n >= 5 and len(order[0]) == 1
+    for i in range(n):
+        st = tuple((v // 10000, v % 10000) for v in order[i])
+        for a in range(4):
+            nxt, mv = oz.get_next_state_moved(st, a)
+            assert succ[i, a].tolist() == p2d(nxt) and int(moved[i, a]) == (1 if mv else 0)
+            assert bool(goal[i, a]) == oz.py.is_goal_state(nxt)  # vacuously true
 
 
 def test_cpp_known_answers():
