@@ -237,7 +237,7 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       of the set the kernels carry no row loops at all; 2 none; 3 only the puzzles with a movable
                                       beyond 8 x 8 cells (kernels with both paths).  Setting it rebuilds the tables (synchronises
                                       the device) */
-#define PW_OPT_STEP_TABLE_BYTES 17   /* read-only: bytes of overlap tables in HBM */
+#define PW_OPT_STEP_TABLE_BYTES 17   /* read-only: bytes of overlap tables (and, for engines of at most 64 puzzles, push tables) in HBM */
 #define PW_OPT_STEP_TABLE_PUZZLES 18 /* read-only: puzzles of the set that have overlap tables */
 #define PW_OPT_STEP_NARROW_GROUPS 19 /* sets with 9..16 movables per puzzle (N_pad 16): 8 lanes per environment, two movables per lane
                                       (8 environments per wavefront) instead of 16 lanes: 0 automatic (with the table-only
@@ -250,7 +250,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       instructions per environment than a lane group, but an eighth of the wavefronts -- it wins
                                       once the batch alone fills the chip; needs overlap tables for every puzzle of the set).
                                       0 = default (131 072 for sets with up to 16 movables per puzzle; N_pad 32 sets: 196 608 for
-                                      one step per launch, 393 216 for pw_rollout); a threshold no batch reaches (2^31) = never */
+                                      one step per launch, 393 216 for pw_rollout); a threshold no batch reaches (2^31) = never.
+                                      Also the number of states from which pw_expand4 and the passes of pw_search_expand run one
+                                      lane per state (default 131 072; PW_OPT_STEP_KERNEL lane forces it for every size) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order
@@ -384,7 +386,11 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
  *   states int32 [F][N]      Position2D = x * 10000 + y   (pushworld_puzzle.h:32-37)
  *   succ   int32 [F][4][N]
  *   moved  uint32 [F][4]     bit k set <=> object k is in moved_object_indices (cc:446-457)
- *   goal   uint8 [F][4]      satisfiesGoal(successor) */
+ *   goal   uint8 [F][4]      satisfiesGoal(successor)
+ * Frontiers of >= 131 072 states of a puzzle with at most 16 movables run one LANE per state (engines of at most 64
+ * puzzles: they carry the reference's collision tables with the four actions interleaved, 4 bits per relative offset, one
+ * lookup per push test); smaller ones and other puzzles one lane group per state.  Same results either way; the buffers need
+ * no particular alignment (16-byte aligned ones leave in wider stores).  PW_OPT_STEP_LANE_BATCH moves the threshold. */
 int pw_expand4(PwEngine* e, int32_t puzzle, const int32_t* states, int32_t* succ,
                uint32_t* moved, uint8_t* goal, int32_t num_states, void* stream);
 
