@@ -253,6 +253,11 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       one step per launch, 393 216 for pw_rollout); a threshold no batch reaches (2^31) = never.
                                       Also the number of states from which pw_expand4 and the passes of pw_search_expand run one
                                       lane per state (default 131 072; PW_OPT_STEP_KERNEL lane forces it for every size) */
+#define PW_OPT_STEP_BOARDS 22        /* sets whose puzzles ALL fit into 8 x 8 cells (grid with its border walls: the 5 x 5 Level-0
+                                      families) and have at most 8 movables: state-only launches (pw_step, pw_rollout) run one lane
+                                      per environment on whole-grid uint64 boards -- registers only, no table lookups.
+                                      0 (default) automatic, 2 never (the lane groups) */
+#define PW_OPT_STEP_BOARD_SET 23     /* read-only: 1 when the engine's set qualifies for PW_OPT_STEP_BOARDS */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

@@ -172,10 +172,15 @@ OPTIONS = {
     "step_table_puzzles": 18,  # read-only
     "step_narrow_groups": 19,  # N_pad 16: 8-lane groups with two movables per lane
     "step_block_order": 20,    # 0 / "forward", 1 / "reverse": which end of the batch the step kernel starts with
+    "step_boards": 22,         # sets of 8 x 8 puzzles, state only: 0 / "auto" whole-grid boards in registers, 2 / "never"
+    "step_board_set": 23,      # read-only: the set qualifies
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2,
                   "forward": 0, "reverse": 1, "never": 2**31}
+
+
+_OPTION_VALUES_BY_KEY = {"step_boards": {"auto": 0, "never": 2}}
 
 
 def _load():
@@ -497,7 +502,12 @@ class Engine:
         """``pw_engine_set_option``: ``key`` is a name of ``OPTIONS`` (or its number), ``value`` an integer or
         one of "group" / "wave" / "lane" (step_kernel), "auto" / "lds" (render_kernel)."""
         k = OPTIONS[key] if isinstance(key, str) else int(key)
-        v = _OPTION_VALUES[value] if isinstance(value, str) else int(value)
+        if isinstance(value, str):  # (a few names mean different numbers for different options)
+            v = _OPTION_VALUES_BY_KEY.get(key, {}).get(value, _OPTION_VALUES.get(value))
+            if v is None:
+                raise ValueError(f"unknown value {value!r} for option {key!r}")
+        else:
+            v = int(value)
         check(lib.pw_engine_set_option(self.handle, k, v))
 
     def get_option(self, key) -> int:

@@ -114,6 +114,9 @@ struct PwEngine {
                            // 1 every puzzle, 2 none
   uint64_t* d_ovl;         // overlap tables of all puzzles that have them (word 0 unused)
   PwOvlDir* d_ovl_dir;     // [set size]
+  uint64_t* d_boards;      // [set size][2] whole-grid wall / wall + agent-wall boards when EVERY puzzle fits 8 x 8 cells and has at
+                           // most 8 movables (pw_step_board_kernel), else NULL
+  int step_boards;         // PW_OPT_STEP_BOARDS: 0 automatic (state-only launches of such sets), 2 never
   PwPushDir* d_push_dir;   // [set size], or NULL (sets of more than 64 puzzles carry no push tables)
   std::vector<uint8_t> push_has;  // [set size] host copy: puzzle p has push tables
   int64_t ovl_bytes;

@@ -28,9 +28,13 @@ def puzzles(golden):
     return {k: PushWorldPuzzle(text=golden.text(k)) for k in golden.keys}
 
 
-def _groups(golden):
-    g = {"bench": [], "tests": [], "l0": [], "level1": []}
+def _groups(golden, puzzles=None):
+    g = {"bench": [], "tests": [], "l0": [], "level1": [], "tiny": []}
     for k in golden.keys:
+        if puzzles is not None:  # grid with its border walls within 8 x 8, at most 8 movables: pw_step_board_kernel's sets
+            w, h = puzzles[k].dimensions
+            if w <= 8 and h <= 8 and puzzles[k].num_movables <= 8:  # (dimensions include the border)
+                g["tiny"].append(k)
         if k.startswith("bench:level1/"):
             g["level1"].append(k)  # at most 11 movables: an N_pad 16 pool (also part of "bench")
         if k.startswith("bench:"):
@@ -48,25 +52,27 @@ def _step_options(kernel):
     default of multi-step rollouts), "group-wide" (32-lane groups), "lane", "wave"; "group-tables" / "group-notables":
     overlap tables (PW_OPT_STEP_TABLES) for every puzzle / for none (default: for puzzles with movables beyond 8 x 8)."""
     if kernel == "group-narrow":  # N_pad 16 pools: 8 lanes per environment, two movables per lane
-        return {"step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 1}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 1}
     if kernel == "group-tables":
-        return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "all"}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_tables": "all"}
     if kernel == "group-bigtables":  # tables only for the puzzles with big movables: the kernel instance with both paths
-        return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "big"}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_tables": "big"}
     if kernel == "group-bigtables-lds":
-        return {"step_kernel": "group", "step_lds_tables": 1, "step_tables": "big"}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 1, "step_tables": "big"}
     if kernel == "group-notables":
-        return {"step_kernel": "group", "step_lds_tables": 2, "step_tables": "none"}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_tables": "none"}
     if kernel == "group-lds":  # (the table-only kernels have nothing to stage: row loops, rows in LDS)
-        return {"step_kernel": "group", "step_lds_tables": 1, "step_tables": "none"}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 1, "step_tables": "none"}
     if kernel == "group-wide":  # N_pad 32 pools: 32 lanes per environment instead of two movables per lane
-        return {"step_kernel": "group", "step_lds_tables": 2, "step_wide_groups": 1}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_wide_groups": 1}
+    if kernel == "boards":  # sets of 8 x 8 puzzles: whole-grid boards in registers (the default for state-only launches there)
+        return {"step_kernel": "group", "step_lds_tables": 2}
     if kernel == "big-batch":  # what state-only launches of >= 131 072 environments pick by themselves (PW_OPT_STEP_LANE_BATCH)
-        return {"step_kernel": "group", "step_lds_tables": 2, "step_lane_batch": 1}
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_lane_batch": 1}
     if kernel == "lane-notables":  # one lane per environment with the row loops (the engine has no tables)
-        return {"step_kernel": "lane", "step_lds_tables": 2, "step_tables": "none"}
+        return {"step_boards": "never", "step_kernel": "lane", "step_lds_tables": 2, "step_tables": "none"}
     # "group", "lane": the defaults (tables for every puzzle: the loop-free instances); "wave": rows only
-    return {"step_kernel": kernel, "step_lds_tables": 2}
+    return {"step_kernel": kernel, "step_lds_tables": 2, "step_boards": "never"}
 
 
 @pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
@@ -79,6 +85,7 @@ def _step_options(kernel):
                                           ("bench", "lane"), ("tests", "lane"), ("l0", "lane"), ("level1", "lane"),
                                           ("bench", "lane-notables"), ("tests", "lane-notables"),
                                           ("bench", "big-batch"), ("l0", "big-batch"),
+                                          ("tiny", "boards"), ("tiny", "group"),
                                           ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
@@ -88,8 +95,9 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
     torch = torch_mod
     from pushworld_amd.vec_env import VecPushWorld
 
-    keys = _groups(golden)[group]
+    keys = _groups(golden, puzzles)[group]
     pool = [puzzles[k] for k in keys]
+    assert len(keys) >= 20 or group != "tiny"
     envs = []  # (pool index, key, seq tuple)
     for pi, k in enumerate(keys):
         for seq in golden.sequences(k):
@@ -99,6 +107,9 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
     max_steps = 50
     vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=max_steps, observation=None, device=0,
                        engine_options=_step_options(kernel))
+    if group == "tiny":  # the set qualifies for the whole-grid boards; "boards" runs them, "group" the lane groups
+        assert vec.engine.get_option("step_board_set") == 1
+        assert vec.engine.get_option("step_boards") == (0 if kernel == "boards" else 2)
     vec.reset()
     NP = vec.num_objects_padded
     # start states
@@ -138,7 +149,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
 
 
 @pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-tables", "group-notables", "group-bigtables", "lane",
-                                    "lane-notables", "wave"])
+                                    "lane-notables", "wave", "boards"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
@@ -146,6 +157,10 @@ def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypat
     from pushworld_amd.vec_env import VecPushWorld
 
     keys = [k for k in golden.keys if f"{k}|in" in golden.states]
+    if kernel == "boards":  # only sets of 8 x 8 puzzles run on whole-grid boards
+        tiny = set(_groups(golden, puzzles)["tiny"])
+        keys = [k for k in keys if k in tiny]
+        assert len(keys) >= 10
     pool = [puzzles[k] for k in keys]
     ids, rows = [], []
     for pi, k in enumerate(keys):
@@ -416,7 +431,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
 
 
 @pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-notables", "group-bigtables", "group-level1",
-                                    "group-narrow", "lane", "lane-notables", "big-batch"])
+                                    "group-narrow", "lane", "lane-notables", "big-batch", "boards"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):
     """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's
@@ -431,6 +446,8 @@ def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, ke
     if kernel in ("group-level1", "group-narrow"):
         keys = [k for k in golden.keys if k.startswith("bench:level1/")]
         kernel = "group" if kernel == "group-level1" else kernel
+    if kernel == "boards":  # sets of 8 x 8 puzzles (whole-grid boards in registers; history and bad actions as everywhere)
+        keys = _groups(golden, puzzles)["tiny"]
     pool = [puzzles[k] for k in keys]
     envs = []
     for pi, k in enumerate(keys):

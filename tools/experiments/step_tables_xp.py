@@ -59,6 +59,9 @@ def workloads(which, B=65536):
     if "l0" in which:
         l0 = [_capi.ParsedPuzzle(t) for t in bd.level0_texts(("all",), "train", 2000).values()]
         yield "65536 over 2000 L0 'all'", _capi.PuzzleSet(l0, 0), B, (np.arange(B, dtype=np.int64) * len(l0)) // B
+    if "l0tiny" in which:  # the 5 x 5 families: every puzzle fits 8 x 8 with its border (pw_step_board_kernel)
+        l0 = [_capi.ParsedPuzzle(t) for t in bd.level0_texts(("base", "walls", "goals", "obstacles", "shapes"), "train", 400).values()]
+        yield "%d 5x5 Level-0 puzzles" % len(l0), _capi.PuzzleSet(l0, 0), B, (np.arange(B, dtype=np.int64) * len(l0)) // B
     hi = level_texts((1, 2, 3, 4))
     if "c4" in which:
         texts = list(bd.level0_texts().values())
@@ -98,6 +101,8 @@ def main():
                 opts["step_block_order"] = "forward"
             if "+lane" in mode and "+nolane" not in mode:  # one lane per environment (table-driven when every puzzle has tables)
                 opts["step_kernel"] = "lane"
+            if "+noboards" in mode:  # sets of 8 x 8 puzzles: the lane groups instead of the whole-grid boards in registers
+                opts["step_boards"] = "never"
             if "+nolane" in mode:  # lane groups whatever the batch size
                 opts["step_lane_batch"] = "never"
             if "+rev" in mode:
