@@ -138,6 +138,34 @@ def test_lane_kernel_with_unaligned_buffers_and_ragged_sizes(golden, key):
             assert int((raw[2][:off] != 77).sum()) == 0 and int((raw[2][off + F * 4:] != 77).sum()) == 0
 
 
+@pytest.mark.parametrize("kernel", ["group", "lane"])
+def test_overlapping_states_against_the_reference(golden, kernel):
+    """Random in-bounds states of the fixtures in which movables overlap each other and walls, with the successors the
+    REFERENCE computed for them (tests/golden/make_golden.py): pins the not-already-overlapping clause of the collision
+    tables (puzzle.py:522-593) for the expansion kernels -- the lane kernel answers from the push tables, whose nibbles
+    are built with exactly that clause."""
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    n_states = n_puzzles = 0
+    for k in golden.keys:
+        if f"{k}|in" not in golden.states:
+            continue
+        st = golden.states[f"{k}|in"].astype(np.int64)            # [S][N][2]
+        want = golden.states[f"{k}|out"].astype(np.int64)         # [S][4][N][2]
+        pz = PushWorldPuzzle(text=golden.text(k))                 # the reference's own object order
+        pz._engine().set_option("step_kernel", kernel)
+        succ, moved, goal = pz.expand4(st[:, :, 0] * 10000 + st[:, :, 1])
+        got = succ.cpu().numpy().astype(np.int64)
+        assert (got == want[:, :, :, 0] * 10000 + want[:, :, :, 1]).all(), k
+        mv = moved.cpu().numpy().astype(np.uint32)
+        changed = (want != st[:, None]).any(axis=3)               # [S][4][N]: who moved
+        bits = (changed * (1 << np.arange(changed.shape[2], dtype=np.uint32))).sum(axis=2).astype(np.uint32)
+        assert (mv == bits).all(), k
+        n_states += st.shape[0]
+        n_puzzles += 1
+    assert n_puzzles >= 20 and n_states >= 500
+
+
 def test_lane_kernel_on_an_agent_alone():
     """N = 1 (an agent, walls, nothing to push, no goal): rows of one Position2D, divisions by one in the staging code."""
     from oracle import c_oracle
