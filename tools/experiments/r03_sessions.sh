@@ -140,5 +140,33 @@ timeout 600 python bench.py > $O/r03_bench_final5.json 2> $O/r03_bench_final5.er
 cp profiles/bench_n1_latest.json $O/bench_n1_latest.json 2>/dev/null
 tail -n 1 $O/r03_smoke.txt; tail -n 3 $O/r03_gputest.txt; cut -c1-200 $O/r03_bench_final5.json
 ;;
+20)  # GPU sessions 20-24: one lane per environment (table-driven) against the lane groups over batch sizes; RCCL with one rank.
+for b in 65536 131072 262144 524288 1048576; do
+  timeout 900 python tools/experiments/step_tables_xp.py --which l0,c3,l14 --modes all+nolane,all+lane --reps 100 --batch $b >> $O/r03_lane_xp.txt 2>&1
+done
+timeout 600 python -m pytest tests/test_gpu_bench.py -x -q -k rccl 2>&1 | tail -n 3
+;;
+25)  # GPU sessions 25-35: pw_expand4 and the search with one lane per state: parity, rates, counters, staging variants.
+timeout 900 python -m pytest tests/test_gpu_expand.py tests/test_gpu_search.py -x -q 2>&1 | tail -n 3
+timeout 900 python tools/bench_expand.py --sizes 65536,131072,1000000 > $O/r03_expand4_lanes.txt 2>&1
+timeout 900 python tools/bench_search.py --max-states 20000000 --groups > $O/r03_search_groups.json 2>/dev/null
+timeout 900 python tools/bench_search.py --max-states 20000000 > $O/r03_search_lanes.json 2>/dev/null
+( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && \
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
+            --kernel-trace -d $O/prof_expand -o sq1 -- python tools/bench_expand.py --sizes 1000000 > $O/prof_expand_sq1.log 2>&1 && \
+  python tools/rocprof_summary.py $O/prof_expand/sq1_results.db | grep -i "expand4\|^kernel"; rm -rf $O/prof_expand )
+;;
+36)  # GPU sessions 36-40: the whole-grid board kernel: parity, rates against the lane groups, configs.
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_abi.py tests/test_gpu_configs.py -x -q -k "boards or tiny or c2 or bad or garbage or rollout" 2>&1 | tail -n 3
+for b in 65536 1048576; do
+  timeout 900 python tools/experiments/step_tables_xp.py --which c2,l0tiny --modes all+noboards,all --reps 200 --batch $b >> $O/r03_boards_xp.txt 2>&1
+done
+timeout 600 python tools/bench_configs.py > $O/r03_configs2.json 2> $O/r03_configs2.err
+;;
+41)  # GPU session 41: final code: the whole GPU suite, profiles (trace, counters, PMC record), loop-gap experiment.
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -n 2
+bash tools/collect_profiles.sh r03d 2>&1 | tail -n 2
+timeout 600 python tools/experiments/loop_gap_xp.py > $O/r03_loop_gap.txt 2>&1
+;;
 *) echo "usage: $0 <session number>"; exit 2 ;;
 esac
