@@ -241,7 +241,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_STEP_TABLE_PUZZLES 18 /* read-only: puzzles of the set that have overlap tables */
 #define PW_OPT_STEP_NARROW_GROUPS 19 /* sets with 9..16 movables per puzzle (N_pad 16): 8 lanes per environment, two movables per lane
                                       (8 environments per wavefront) instead of 16 lanes: 0 automatic (with the table-only
-                                      kernels), 1 always, 2 never */
+                                      kernels), 1 always, 2 never.  N_pad 32 sets with the table-only kernels: 0 / 1 workgroups of
+                                      32 environments run 8-lane groups unless one of them has more than 16 movables, 2 never
+                                      (16-lane groups for every environment) */
 #define PW_OPT_STEP_BLOCK_ORDER 20   /* lane-group step kernels: 0 workgroups take the environments in index order, 1 in reverse --
                                       for batches sorted by puzzle whose expensive puzzles (many / big movables) come last:
                                       they then start first and the cheap ones fill the tail of the launch */

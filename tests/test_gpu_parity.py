@@ -53,6 +53,8 @@ def _step_options(kernel):
     overlap tables (PW_OPT_STEP_TABLES) for every puzzle / for none (default: for puzzles with movables beyond 8 x 8)."""
     if kernel == "group-narrow":  # N_pad 16 pools: 8 lanes per environment, two movables per lane
         return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 1}
+    if kernel == "group-16lanes":  # N_pad 32 pools: 16-lane groups for every environment (default: 8-lane groups where N <= 16)
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 2}
     if kernel == "group-tables":
         return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_tables": "all"}
     if kernel == "group-bigtables":  # tables only for the puzzles with big movables: the kernel instance with both paths
@@ -77,7 +79,7 @@ def _step_options(kernel):
 
 @pytest.mark.parametrize("group,kernel", [("bench", "group"), ("tests", "group"), ("l0", "group"),
                                           ("bench", "group-lds"), ("tests", "group-lds"), ("l0", "group-lds"),
-                                          ("bench", "group-wide"),
+                                          ("bench", "group-wide"), ("bench", "group-16lanes"),
                                           ("bench", "group-tables"), ("tests", "group-tables"), ("l0", "group-tables"),
                                           ("bench", "group-notables"), ("tests", "group-notables"),
                                           ("bench", "group-bigtables"), ("bench", "group-bigtables-lds"),
@@ -148,8 +150,8 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-tables", "group-notables", "group-bigtables", "lane",
-                                    "lane-notables", "wave", "boards"])
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-16lanes", "group-tables", "group-notables", "group-bigtables",
+                                    "lane", "lane-notables", "wave", "boards"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
@@ -430,7 +432,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
                 assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-notables", "group-bigtables", "group-level1",
+@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-16lanes", "group-notables", "group-bigtables", "group-level1",
                                     "group-narrow", "lane", "lane-notables", "big-batch", "boards"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):

@@ -95,7 +95,9 @@ def main():
     for name, pool, B, ids in workloads(args.which.split(","), args.batch):
         for mode in args.modes.split(","):
             opts = {"step_tables": mode.split("+")[0]}
-            if "+narrow" in mode:
+            if "+16lanes" in mode:  # N_pad 32: 16-lane groups for every environment
+                opts["step_narrow_groups"] = 2
+            elif "+narrow" in mode:
                 opts["step_narrow_groups"] = 1
             if "+fwd" in mode:   # (VecPushWorld picks the reverse order by itself when the expensive puzzles come last)
                 opts["step_block_order"] = "forward"
