@@ -483,7 +483,7 @@ def main():
             # reset: same bytes, the fastest of 16 page orders / occupancies for THIS observation buffer)
             "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
                               "allocations_tried": len(vec.tuned_candidates_ms),
-                              "allocations_max": args.tune_allocations if args.tune_allocations is not None else "product default (<= 20)",
+                              "allocations_max": args.tune_allocations if args.tune_allocations is not None else "product default (<= 32, within a third of the device memory)",
                               "allocator": ("pw_obs_alloc_tuned (HIP virtual-memory chunks; losers released to the device)"
                                             if getattr(vec, "obs_owned_by_library", False) else "torch (caller-owned buffer, tuned in place)"),
                               "torch_reserved_bytes": int(torch.cuda.memory_reserved(dev)),

@@ -51,7 +51,7 @@ class VecPushWorld:
             Default: on for observation buffers of 256 MB and more, where the choice is worth 5-15 %.
         tune_allocations: with ``tune``: the observation buffer is allocated BY THE LIBRARY (``pw_obs_alloc_tuned``:
             physical chunks mapped with the HIP virtual-memory API) from up to this many candidate allocations
-            (default: up to 20, within a third of the device memory).  What the HBM-write-bound render reaches
+            (default: up to 32, within a third of the device memory: 25 for the C3 batch).  What the HBM-write-bound render reaches
             on a buffer follows the buffer's physical backing -- two classes, 7-10 % apart, per allocation
              -- so the library takes a quick look (~10 ms) at one candidate after the other, all
             alive at once, keeps the first of the fast class, releases the others to the DEVICE and tunes on the kept one (nothing stays behind in
@@ -123,13 +123,14 @@ class VecPushWorld:
             nbytes = self.num_envs * self.engine.obs_stride
             if tune is None:
                 tune = nbytes >= (256 << 20)
-            if tune and tune_allocations is None:  # as many as fit into a third of the device memory, at most 20
+            if tune and tune_allocations is None:  # as many as fit into a third of the device memory, at most 32
                 # (of the TOTAL memory: torch.cuda.mem_get_info() was seen returning 0 free bytes on these boxes;
                 # the library chooses among the candidates there are when memory runs out)
                 total = torch.cuda.get_device_properties(self.device).total_memory
-                # (20: on a box whose allocations are mostly of the slow class -- one in six to twelve fast, profiles/r03_trace_bench_line.json --
-                # twelve candidates still miss one time in four; a candidate costs ~40 ms and goes back to the device)
-                tune_allocations = min(20, max(1, int(total // 3 // nbytes)))
+                # (on a box whose allocations are mostly of the slow class -- one in six to thirteen fast,
+                # profiles/r03_trace_bench_line.json, r03_bench_final7.json: the 14th candidate was the first fast one -- twelve
+                # candidates miss one time in three; a candidate costs ~40 ms and goes back to the device)
+                tune_allocations = min(32, max(1, int(total // 3 // nbytes)))
             owned = False
             if tune and tune_allocations:
                 # library-owned buffer: candidates are tuned on the initial states (reset() draws them again)
