@@ -28,7 +28,9 @@ the dominant kernel (render; HBM bound), timed live by HIP events the library re
 the launch stream (``PW_OPT_PROFILE_RENDER``), and ``cpu_baseline`` = the C restatement of the reference
 algorithm (oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample, with 1 thread and
 with all threads, plus the pure-Python restatement of the reference environment (the reference's own Python
-env cannot travel to the GPU box) on 1 core and on P processes.
+env cannot travel to the GPU box) on 1 core and on P processes.  Non-headline extras of the c3 line (``--no-extras`` drops
+them): ``incremental_render`` (the persistent observation buffer maintained by pw_step_render_delta), ``state_only_rollout``
+(64 steps per launch) and ``expand4`` (config C5: pw_expand4 on a ~1 M-state frontier of `Four Pistons`).
 """
 import argparse
 import json
@@ -643,6 +645,43 @@ def main():
                                           "steps_per_launch": Tn, "envs": B, "n_gpus": 1}
         except Exception as exc:  # noqa: BLE001
             out["state_only_rollout"] = {"error": repr(exc)}
+        # extra (not the headline): config C5 of BASELINE.json -- pw_expand4 on a frontier of ~1 M distinct states of
+        # `Four Pistons` (N = 12) collected by the GPU breadth-first search; 20 N + 20 algorithmic bytes per parent
+        if args.config == "c3":
+            try:
+                from pushworld_amd.puzzle import PushWorldPuzzle
+                from pushworld_amd.search import BreadthFirstSearch
+
+                pz = PushWorldPuzzle(os.path.join(ROOT, "pushworld_amd", "data", "puzzles", "level4", "Four Pistons.pwp"), order="cpp")
+                bfs = BreadthFirstSearch(pz, max_states=3_000_000)
+                bfs.begin()
+                while bfs.total_states < 1_000_000 and not bfs.exhausted:
+                    bfs.expand()
+                F = min(bfs.total_states, 1_000_000)
+                xy = bfs.states(0, F)
+                bfs.close()
+                st = torch.as_tensor((xy[:, :, 0].astype(np.int64) * 10000 + xy[:, :, 1]).astype(np.int32)).to(dev)
+                N = st.shape[1]
+                succ = torch.empty((F, 4, N), dtype=torch.int32, device=dev)
+                moved = torch.empty((F, 4), dtype=torch.int32, device=dev)
+                goal = torch.empty((F, 4), dtype=torch.uint8, device=dev)
+                peng = pz._engine()
+                peng.expand4(0, st, succ, moved, goal)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    peng.expand4(0, st, succ, moved, goal)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                out["expand4"] = {"parents_per_s": F / (ms * 1e-3), "states": int(F), "movables": int(N), "puzzle": "level4/Four Pistons",
+                                  "ms": ms, "algorithmic_gbs": F * (20 * N + 20) / (ms * 1e-3) / 1e9,
+                                  "frac_of_hbm_peak": F * (20 * N + 20) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "config C5 (pw_expand4, one lane per state); bit-exact vs the C oracle on such frontiers in "
+                                          "tests/test_gpu_expand.py; not the headline value"}
+            except Exception as exc:  # noqa: BLE001
+                out["expand4"] = {"error": repr(exc)}
     if not args.no_cpu_baseline:
         # rank 0's host cores, also for N > 1 (the other ranks have finished; their processes are idle or gone)
         fh, fw = eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc

@@ -106,6 +106,18 @@ def test_single_rank_line_has_the_contract_fields():
     assert d["config"]["workload"].startswith("C3") and d["roofline"]["kernel"].startswith("pw_render")
 
 
+def test_extras_of_the_line_run():
+    """The non-headline extras of the line (incremental render, state-only rollouts, config C5's pw_expand4 on a ~1 M-state
+    frontier) run and report numbers, not errors."""
+    proc, lines = run_bench("--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-cpu-baseline")
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    d = lines[0]
+    for key in ("incremental_render", "state_only_rollout", "expand4"):
+        assert key in d and "error" not in d[key], (key, d.get(key))
+    x = d["expand4"]
+    assert x["states"] >= 500_000 and x["movables"] == 12 and x["parents_per_s"] > 1e9 and 0 < x["frac_of_hbm_peak"] < 1
+
+
 @pytest.mark.parametrize("obs", ["none", "uint8"])
 def test_c4_shard_runs(obs):
     """--config c4: the rank's shard of the full mix (all 14 000 Level-0 train puzzles + Levels 1-4, N_pad 32,
