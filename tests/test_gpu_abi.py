@@ -305,6 +305,35 @@ def test_block_order_is_chosen_from_the_batch_and_never_changes_results(torch_mo
     assert torch.equal(vecs["auto-up"].pos, vecs["forced"].pos) and torch.equal(ru[0], rf[0])
 
 
+def test_mixed_group_widths_on_an_unsorted_batch(torch_mod, golden):
+    """N_pad 32 sets: workgroups of 32 environments run 8-lane groups unless one of their environments has more than 16
+    movables (pw_step_group_mixed_kernel).  A batch in RANDOM puzzle order (wide and narrow workgroups interleaved, a ragged
+    last workgroup), one step per launch and as a rollout (twin workgroups), against 16-lane groups for every environment."""
+    torch = torch_mod
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith("bench:")]
+    pool = [PushWorldPuzzle(text=golden.text(k)) for k in keys]
+    assert max(p.num_movables for p in pool) > 16
+    B = 5003
+    ids = np.random.default_rng(11).integers(0, len(pool), B)
+    mk = lambda opts: VecPushWorld(pool, B, puzzle_ids=ids, max_steps=30, observation=None, device=0, autoreset=True,  # noqa: E731
+                                   engine_options=opts)
+    mixed, wide = mk({}), mk({"step_narrow_groups": 2})
+    assert mixed.num_objects_padded == 32
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    acts = torch.randint(0, 4, (40, B), generator=g, device="cuda:0", dtype=torch.uint8)
+    mixed.reset()
+    wide.reset()
+    for t in range(24):
+        a, b = mixed.step(acts[t]), wide.step(acts[t])
+        assert torch.equal(mixed.pos, wide.pos) and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:])), t
+    ha, hb = mixed.rollout(acts, history=True), wide.rollout(acts, history=True)
+    assert torch.equal(mixed.pos, wide.pos) and torch.equal(mixed.steps, wide.steps)
+    assert all(torch.equal(x, y) for x, y in zip(ha, hb))
+
+
 def test_big_state_only_batches_run_one_lane_per_environment(torch_mod):
     """PW_OPT_STEP_LANE_BATCH: a state-only launch of >= 131 072 environments (N_pad <= 16 sets) runs the one-lane-per-
     environment formulation by itself; same results as the lane groups (option "never"), step by step and as a rollout."""
