@@ -398,7 +398,7 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
  *   succ   int32 [F][4][N]
  *   moved  uint32 [F][4]     bit k set <=> object k is in moved_object_indices (cc:446-457)
  *   goal   uint8 [F][4]      satisfiesGoal(successor)
- * Frontiers of >= 131 072 states of a puzzle with at most 16 movables run one LANE per state (engines of at most 64
+ * Frontiers of >= 131 072 states run one LANE per state (engines of at most 64
  * puzzles: they carry the reference's collision tables with the four actions interleaved, 4 bits per relative offset, one
  * lookup per push test); smaller ones and other puzzles one lane group per state.  Same results either way; the buffers need
  * no particular alignment (16-byte aligned ones leave in wider stores).  PW_OPT_STEP_LANE_BATCH moves the threshold. */

@@ -64,6 +64,7 @@ def bfs(puzzle, max_states):
     "bench:level2/Pull Dont Push.pwp|lanes", "bench:level4/Four Pistons.pwp|lanes", "bench:level4/Mind The Gap.pwp|lanes",
     "bench:level3/Armor.pwp|lanes", "bench:level3/Rocky Shore.pwp|lanes", "bench:level2/Bubbles.pwp|lanes",
     "bench:level3/Moving Mountains.pwp|lanes", "bench:level1/A Tight Squeeze.pwp|lanes",  # (N = 2: rows of one word)
+    "bench:level2/Clean Sweep.pwp|lanes",  # 19 movables: the instance with 32 bits per action
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle
@@ -98,7 +99,7 @@ def test_bfs_layers_match_oracle(golden, key):
 
 
 @pytest.mark.parametrize("key", ["bench:level1/2 Obstacle.pwp", "bench:level2/Pull Dont Push.pwp", "bench:level4/Four Pistons.pwp",
-                                 "bench:level4/Mind The Gap.pwp", "bench:level1/Pulling.pwp"])
+                                 "bench:level4/Mind The Gap.pwp", "bench:level1/Pulling.pwp", "bench:level2/Clean Sweep.pwp"])
 def test_lane_kernel_with_unaligned_buffers_and_ragged_sizes(golden, key):
     """pw_expand4_lane_kernel picks its store width (16 / 8 / 4 bytes) and how many actions it stages at a time from N
     and from the alignment of the caller's buffers: output buffers that start 4 bytes (succ, moved) / 1 byte (goal) into
