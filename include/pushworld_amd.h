@@ -16,11 +16,12 @@
  *     the buffer pointers (an empty tensor's data pointer is NULL);
  *   - "device pointers" are caller-owned HBM buffers (e.g. tensor.data_ptr());
  *     `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
- *     are asynchronous on that stream; the engine never allocates per call, with two exceptions on FIRST USE OR
- *     BATCH GROWTH only: the page-ordered render (pw_render / pw_step_render) keeps a 16 B / environment record
- *     array, pw_step_render_delta a 4 B / environment one.  They are engine-owned scratch written and read by the
- *     kernels of one call, so all calls on one engine must go to ONE stream (or be event-ordered by the caller), and
- *     the first call of a batch size must not sit inside a graph capture (pw_obs_alloc allocates the records up front).
+ *     are asynchronous on that stream; the engine never allocates per call.  Its per-environment scratch (a 16 B
+ *     record per environment for the page-ordered render, 4 B for pw_step_render_delta) is allocated by
+ *     pw_engine_create when PwEngineConfig::max_batch is given (or by pw_obs_alloc for its batch); with max_batch 0 the
+ *     first call of a batch size allocates it, and that one call must not sit inside a graph capture.  The records are
+ *     written and read by the kernels of one call, so all calls on one engine must go to ONE stream (or be
+ *     event-ordered by the caller).
  *   - no entry point changes the calling thread's current HIP device: everything an engine /
  *     set / search allocates or launches lands on the device of its puzzle set, and the
  *     caller's device is restored on return.
@@ -46,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PW_ABI_VERSION 3
+#define PW_ABI_VERSION 4
 
 /* error codes */
 #define PW_OK 0
@@ -96,6 +97,11 @@ typedef struct PwEngineConfig {
   int32_t obs_dtype;        /* PW_OBS_U8 | PW_OBS_F32                                     */
   int32_t pad_cell_height;  /* observation frame in cells (env_utils.py:44-91);           */
   int32_t pad_cell_width;   /*   0 = maximum over the puzzle set (gym_env.py:80-82)       */
+  int32_t max_batch;        /* > 0: the engine-owned per-environment scratch (page records of the page-ordered
+                               render, dirty-row records of pw_step_render_delta) is allocated by pw_engine_create
+                               for this many environments: no entry point allocates afterwards for batches up to
+                               it, so the FIRST pw_step_render call may already sit inside a HIP graph capture.
+                               0: allocated by the first call of a batch size (never in a steady-state loop)      */
 } PwEngineConfig;
 
 const char* pw_last_error(void);
@@ -308,6 +314,38 @@ int pw_obs_free(PwEngine* e, void* obs);
  * looks at the 0xFF flags can poll this instead (an env flagged 0xFF is reset by the next
  * PW_STEP_AUTORESET step, where the reference raises ValueError, gym_env.py:195-196). */
 int64_t pw_engine_bad_actions(PwEngine* e, void* stream);
+
+/* Throughput counters kept ON THE DEVICE by the step kernels (the one collective of a multi-GPU job
+ * sums this vector).  Every step kernel -- pw_step, pw_rollout, pw_step_render, pw_step_render_delta, whichever
+ * formulation runs -- adds, per wavefront, popcount(ballot(...)) of its environments to engine-owned int64 counters
+ * (64 slots a cache line apart, one atomic per wavefront and non-zero counter):
+ *   out[0]  env-steps: (environment, step) pairs the kernels processed, autoreset steps and refused actions included
+ *   out[1]  episodes ended: steps that returned terminated or truncated (gym_env.py:210-223)
+ *   out[2]  episodes solved: steps that returned terminated (is_goal_state, puzzle.py:409-411)
+ *   out[3]  actions outside 0..3 seen since the engine was created (pw_engine_bad_actions clears its own counter, not this)
+ * pw_counters sums the slots (synchronises `stream`); pw_counters_reset zeroes them (asynchronous on `stream`). */
+#define PW_NUM_COUNTERS 4
+int pw_counters(PwEngine* e, int64_t out[PW_NUM_COUNTERS], void* stream);
+int pw_counters_reset(PwEngine* e, void* stream);
+
+/* Latency path of the single-state API (PushWorldPuzzle.get_next_state, puzzle.py:348-394; is_valid_plan :413-424;
+ * render_plan :471-506): host memory in, host memory out, ONE launch and no copy command.  The state travels in the
+ * kernel arguments, one wavefront computes the step(s), the result is written straight into pinned host memory mapped
+ * into the device, and the call returns as soon as the kernel's completion word arrives (the calling thread polls it;
+ * no stream synchronisation).  Runs on an engine-owned stream; as everything on an engine, not re-entrant.
+ *   xy_in / xy_out  int8 [N][2] of puzzle `puzzle` (N = its num_movables)
+ *   info            optional int32 [4]: moved-object bit mask (bit 0 = agent; 0 = nothing moved), goals achieved before,
+ *                   goals achieved after, is_goal_state(after)
+ * pw_plan_states replays `num_actions` actions from `xy_start` (NULL = the initial state) in one launch:
+ *   states_out      int8 [num_actions + 1][N][2], state 0 = the start
+ *   goal_out        optional uint8 [num_actions + 1]: is_goal_state of every state
+ *   dev_states      optional DEVICE buffer int8 [num_actions + 1][NP][2] (NP = pw_engine_npad) that receives the same
+ *                   states in the pos layout of pw_render, for one batched render of the whole plan
+ * At most PW_PLAN_MAX_ACTIONS actions per call. */
+#define PW_PLAN_MAX_ACTIONS 65536
+int pw_next_state(PwEngine* e, int32_t puzzle, const int8_t* xy_in, int32_t action, int8_t* xy_out, int32_t* info);
+int pw_plan_states(PwEngine* e, int32_t puzzle, const int8_t* xy_start, const uint8_t* actions, int32_t num_actions,
+                   int8_t* states_out, uint8_t* goal_out, int8_t* dev_states);
 
 /* Debug check of the preconditions of the step / render entry points: puzzle_id[i] inside the set; with `pos` != NULL
  * also every movable inside its puzzle's grid (0 <= x <= W - w, 0 <= y <= H - h) and zero padding beyond the puzzle's

@@ -19,10 +19,12 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PUSHWORLD_AMD_LIB") or os.path.join(_HERE, "lib", "libpushworld_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PW_OK = 0
 PW_EINVAL, PW_EPARSE, PW_EGOAL, PW_ELIMIT, PW_EDEVICE, PW_ENOMEM, PW_EELEMENT = -1, -2, -3, -4, -5, -6, -7
 ORDER_PYTHON, ORDER_CPP = 0, 1
+PUZZLE_HEADER_BYTES = 320      # sizeof(PwPuzzleHeader), csrc/pw_format.h (asserted by pw_puzzleset_headers users)
+PUZZLE_HEADER_N_OFFSET = 6     # offsetof(PwPuzzleHeader, N): uint32 base, then uint8 W, H, N, G
 OBS_U8, OBS_F32 = 0, 1
 STEP_AUTORESET = 1
 
@@ -59,6 +61,7 @@ class PwEngineConfig(ctypes.Structure):
         ("obs_dtype", c_int32),
         ("pad_cell_height", c_int32),
         ("pad_cell_width", c_int32),
+        ("max_batch", c_int32),
     ]
 
 
@@ -148,6 +151,10 @@ SIGNATURES = {
     "pw_obs_alloc_tuned": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, POINTER(c_void_p),
                                    POINTER(ctypes.c_float), POINTER(c_int32), c_void_p]),
     "pw_obs_free": (c_int, [c_void_p, c_void_p]),
+    "pw_counters": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
+    "pw_counters_reset": (c_int, [c_void_p, c_void_p]),
+    "pw_next_state": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "pw_plan_states": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
 }
 
 # pw_engine_set_option keys (include/pushworld_amd.h)
@@ -180,7 +187,10 @@ _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds":
                   "forward": 0, "reverse": 1, "never": 2**31}
 
 
-_OPTION_VALUES_BY_KEY = {"step_boards": {"auto": 0, "never": 2}}
+# names that mean different numbers for different options ("never" is a batch threshold for step_lane_batch)
+_OPTION_VALUES_BY_KEY = {"step_boards": {"auto": 0, "never": 2},
+                         "step_narrow_groups": {"auto": 0, "always": 1, "never": 2},
+                         "step_lds_tables": {"auto": 0, "always": 1, "never": 2}}
 
 
 def _load():
@@ -391,6 +401,14 @@ def _ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+# the raw hipStream_t of torch's current stream without building a torch.cuda.Stream object (~0.2 us instead of ~1.5 us;
+# the step entry points are called once per environment step)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+if _raw_stream is None:  # pragma: no cover -- older torch
+    def _raw_stream(device_index):
+        return torch.cuda.current_stream(device_index).cuda_stream
+
+
 class _DLDevice(ctypes.Structure):
     _fields_ = [("device_type", c_int), ("device_id", c_int)]
 
@@ -467,7 +485,7 @@ class Engine:
     enqueue kernels on ``torch.cuda.current_stream()``."""
 
     def __init__(self, pset: PuzzleSet, max_steps=None, pixels_per_cell=20, border_width=2,
-                 obs_dtype=OBS_F32, pad_cell_height=0, pad_cell_width=0, options=None):
+                 obs_dtype=OBS_F32, pad_cell_height=0, pad_cell_width=0, options=None, max_batch=0):
         if max_steps is not None and int(max_steps) < 0:
             raise ValueError("max_steps must be None or >= 0")
         cfg = PwEngineConfig(
@@ -475,6 +493,8 @@ class Engine:
             int(max_steps) if max_steps is not None else -1,
             int(pixels_per_cell), int(border_width), int(obs_dtype),
             int(pad_cell_height), int(pad_cell_width),
+            # engine-owned per-environment scratch sized at creation: no entry point allocates afterwards
+            int(max_batch),
         )
         h = c_void_p()
         check(lib.pw_engine_create(pset.handle, ctypes.byref(cfg), ctypes.byref(h)))
@@ -548,7 +568,64 @@ class Engine:
                              f"(first: environment {first.value})")
 
     def _stream(self):
-        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return c_void_p(_raw_stream(self.device.index))
+
+    def counters(self):
+        """``pw_counters``: dict of the device-side throughput counters (env_steps, episodes_ended, episodes_solved,
+        bad_actions) summed over the engine's step launches so far.  Synchronises the stream."""
+        out = (c_int64 * 4)()
+        check(lib.pw_counters(self.handle, out, self._stream()))
+        return {"env_steps": out[0], "episodes_ended": out[1], "episodes_solved": out[2], "bad_actions": out[3]}
+
+    def counters_reset(self) -> None:
+        check(lib.pw_counters_reset(self.handle, self._stream()))
+
+    # pre-marshalled entry points: the state tensors of a vector environment never move, so their pointers are converted
+    # once; a call then costs one ctypes call with ready arguments (the actions pointer and the stream are the only
+    # per-call values).  The tensors are kept alive by the closure.
+    def bind_step(self, puzzle_id, pos, steps, reward, dgoals, terminated, truncated, flags=0):
+        """Returns ``call(actions_data_ptr)`` == ``step(puzzle_id, actions, pos, ...)`` on the current stream."""
+        fn, h, dev, batch = lib.pw_step, self.handle, self.device.index, pos.shape[0]
+        a = [_ptr(t) for t in (puzzle_id, pos, steps, reward, dgoals, terminated, truncated)]
+        keep = (puzzle_id, pos, steps, reward, dgoals, terminated, truncated)
+
+        def call(actions_ptr, _keep=keep):
+            rc = fn(h, a[0], actions_ptr, a[1], a[2], a[3], a[4], a[5], a[6], batch, flags, _raw_stream(dev))
+            if rc:
+                check(rc)
+        return call
+
+    def bind_step_render(self, puzzle_id, pos, steps, reward, dgoals, terminated, truncated, obs_storage, flags=0,
+                         delta=False):
+        """Returns ``call(actions_data_ptr)`` == ``step_render(...)`` (``delta``: ``step_render_delta``)."""
+        fn = lib.pw_step_render_delta if delta else lib.pw_step_render
+        h, dev, batch, stride = self.handle, self.device.index, pos.shape[0], self.obs_stride
+        a = [_ptr(t) for t in (puzzle_id, pos, steps, reward, dgoals, terminated, truncated, obs_storage)]
+        keep = (puzzle_id, pos, steps, reward, dgoals, terminated, truncated, obs_storage)
+
+        def call(actions_ptr, _keep=keep):
+            rc = fn(h, a[0], actions_ptr, a[1], a[2], a[3], a[4], a[5], a[6], a[7], stride, batch, flags, _raw_stream(dev))
+            if rc:
+                check(rc)
+        return call
+
+    def next_state(self, puzzle_index: int, xy_in, action: int, xy_out, info=None) -> None:
+        """``pw_next_state``: host buffers in / out (bytes-like of 2 N int8 each), one launch, no copy command."""
+        check(lib.pw_next_state(self.handle, puzzle_index, xy_in, action, xy_out, info))
+
+    def plan_states(self, puzzle_index: int, actions: bytes, start=None, dev_states=None):
+        """``pw_plan_states``: (states int8 [T + 1, N, 2], goal flags uint8 [T + 1]) as numpy arrays."""
+        import numpy as np
+
+        T = len(actions)
+        n = self.pset.puzzles[puzzle_index].num_movables if self.pset.puzzles else None
+        if n is None:
+            raise ValueError("plan_states needs a puzzle set built from parsed puzzles")
+        states = np.zeros((T + 1, n, 2), np.int8)
+        goals = np.zeros((T + 1,), np.uint8)
+        check(lib.pw_plan_states(self.handle, puzzle_index, None if start is None else c_void_p(start.ctypes.data),
+                                 actions, T, c_void_p(states.ctypes.data), c_void_p(goals.ctypes.data), _ptr(dev_states)))
+        return states, goals
 
     # state buffers -------------------------------------------------------------------
     def alloc_state(self, batch: int):

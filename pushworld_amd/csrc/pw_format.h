@@ -81,6 +81,12 @@ struct PwPuzzleHeader {
   int8_t init[32][2];     // @256  initial positions
 };
 
+#ifdef __cplusplus
+#include <cstddef>
+// (pushworld_amd/_capi.py reads N out of the packed header array: PUZZLE_HEADER_BYTES / PUZZLE_HEADER_N_OFFSET)
+static_assert(sizeof(PwPuzzleHeader) == 320 && offsetof(PwPuzzleHeader, N) == 6, "PwPuzzleHeader layout is part of the packed set format");
+#endif
+
 // the `off_small` entry of an object with bounding box w x h and shape rows `rows` (bit x of rows[r] = cell (x, r));
 // host side (the device packer in pw_generate.inc builds the same value from its grid rows)
 static inline uint64_t pw_small_board(const uint64_t* rows, int w, int h) {

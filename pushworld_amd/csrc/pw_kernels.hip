@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -110,8 +111,8 @@ struct PwEngine {
   int step_lds_tables;     // PW_OPT_STEP_LDS_TABLES: the group step kernel stages the puzzle's row tables in LDS:
                            // 0 automatic (launches of >= 4 steps), 1 always, 2 never
   bool lds_tables_fit;     // every puzzle of the set has <= 128 shape rows
-  int step_tables;         // PW_OPT_STEP_TABLES: which puzzles get overlap tables: 0 those with a movable beyond 8 x 8,
-                           // 1 every puzzle, 2 none
+  int step_tables;         // PW_OPT_STEP_TABLES: which puzzles get overlap tables: 0 automatic = 1 every puzzle that fits,
+                           // 2 none, 3 only those with a movable beyond 8 x 8
   uint64_t* d_ovl;         // overlap tables of all puzzles that have them (word 0 unused)
   PwOvlDir* d_ovl_dir;     // [set size]
   uint64_t* d_boards;      // [set size][2] whole-grid wall / wall + agent-wall boards when EVERY puzzle fits 8 x 8 cells and has at
@@ -131,12 +132,21 @@ struct PwEngine {
   void* d_rec;             // page records (PageRec [rec_cap]): allocated with the first observation buffer / render
   int64_t rec_cap;         //   call of a batch size, grown (never shrunk) when a larger batch arrives
   std::vector<PwObsBuf> obs_bufs;  // pw_obs_alloc
-  int obs_chunk_mb;        // PW_OPT_OBS_CHUNK_MB: physical chunk size of pw_obs_alloc (0 = the allocation granularity)
+  int obs_chunk_mb;        // PW_OPT_OBS_CHUNK_MB: physical chunk size of pw_obs_alloc in MiB (0 = the default, 32 MiB)
   int obs_accept_gbs;      // PW_OPT_OBS_ACCEPT_GBS: pw_obs_alloc_tuned keeps the first candidate that reaches this
   // PW_OPT_PROFILE_RENDER: HIP event pairs around the dominant (render) launch, on the launch stream
   std::vector<hipEvent_t> prof_events;  // 2 per slot
   int prof_used;
-  uint32_t* d_scratch;     // 64 bytes of device scratch (pw_validate_state counters)
+  uint32_t* d_scratch;     // 64 bytes of device scratch (pw_validate_state counters) + one 4 KiB page of zeros
+  unsigned long long* d_counters;  // PW_COUNTER_SLOTS x 8 uint64: env-steps / episodes ended / solved per slot (pw_counters)
+  int64_t bad_total;       // out-of-range actions pw_engine_bad_actions has read and cleared so far (pw_counters adds the rest)
+  // latency path of the single-state API (pw_next_state / pw_plan_states): created on first use
+  hipStream_t lat_stream;
+  void* lat_host;          // pinned host memory mapped into the device: results + completion word
+  void* lat_dev;           // the device's address of lat_host
+  uint8_t* lat_actions;    // device copy of a plan's actions (PW_PLAN_MAX_ACTIONS bytes)
+  size_t lat_bytes;
+  uint32_t lat_seq;        // completion word of the last launch
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)

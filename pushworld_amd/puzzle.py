@@ -8,8 +8,10 @@ HIP kernels of ``libpushworld_amd.so``; there is no CPU implementation of either
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from dataclasses import dataclass
+from itertools import chain
 from typing import Iterable, List, Optional, Set, Tuple
 
 import numpy as np
@@ -108,6 +110,8 @@ class PushWorldPuzzle:
         self._pset = None
         self._engines = {}
         self._bufs = None
+        self._batch = None  # state buffers of get_next_states
+        self._lat = None    # pre-marshalled pw_next_state call
 
     # ---------------------------------------------------------------- properties
     @property
@@ -179,31 +183,80 @@ class PushWorldPuzzle:
             self._bufs = eng.alloc_state(1)
             self._bufs["pid"] = torch.zeros((1,), dtype=torch.int32, device=eng.device)
             self._bufs["act"] = torch.zeros((1,), dtype=torch.uint8, device=eng.device)
+            # staging of the render path: pinned host copy of the position row, uploaded with one asynchronous copy
+            self._bufs["pos_host"] = torch.zeros((1, eng.np, 2), dtype=torch.int8).pin_memory()
         return self._bufs
 
-    def _upload(self, eng, state) -> None:
-        state = _as_state(state)
+    def _state_bytes(self, state) -> bytes:
+        """The 2 N int8 values of a state as bytes (the wire format of ``pw_next_state``)."""
         if len(state) != self.num_movables:
             raise ValueError(f"state has {len(state)} positions, puzzle has {self.num_movables} movables")
-        host = torch.zeros((1, eng.np, 2), dtype=torch.int8)
-        host[0, : self.num_movables] = torch.tensor(state, dtype=torch.int8)
-        self._state_bufs(eng)["pos"].copy_(host)
+        try:
+            flat = bytes(chain.from_iterable(state))
+        except (ValueError, TypeError):  # negative or non-integer coordinates: int8 two's complement like the kernels read them
+            flat = bytes(int(v) & 0xFF for v in chain.from_iterable(state))
+        if len(flat) != 2 * self.num_movables:
+            raise ValueError("every position of a state is an (x, y) pair")
+        return flat
 
-    def _download(self, eng) -> State:
-        arr = self._bufs["pos"][0, : self.num_movables].cpu().tolist()
-        return tuple((int(x), int(y)) for x, y in arr)
+    def _upload(self, eng, state) -> None:
+        b = self._state_bufs(eng)
+        flat = self._state_bytes(state)
+        host = b["pos_host"]
+        host.view(torch.uint8).view(-1)[: len(flat)] = torch.frombuffer(bytearray(flat), dtype=torch.uint8)
+        b["pos"].copy_(host, non_blocking=True)
 
     # ---------------------------------------------------------------- dynamics
     def get_next_state(self, state: State, action: int) -> State:
-        """puzzle.py:348-394 on the GPU (one wavefront)."""
+        """puzzle.py:348-394 on the GPU: ``pw_next_state`` -- the state travels in the kernel arguments, one wavefront
+        computes the step, the result lands in pinned host memory and the call returns when the kernel's completion
+        word arrives (one launch, no copy command, no stream synchronisation)."""
         if action not in (0, 1, 2, 3):
             raise ValueError("action must be one of 0 (L), 1 (R), 2 (U), 3 (D)")
+        lat = self._lat
+        if lat is None:
+            eng = self._engine()
+            out = ctypes.create_string_buffer(64)
+            lat = self._lat = (_capi.lib.pw_next_state, eng.handle, out, memoryview(out).cast("b"), 2 * self.num_movables, eng)
+        fn, handle, out, view, n2, _ = lat
+        rc = fn(handle, 0, self._state_bytes(state), int(action), out, None)
+        if rc:
+            _capi.check(rc)
+        return tuple(zip(view[0:n2:2], view[1:n2:2]))
+
+    def get_next_states(self, states, actions) -> np.ndarray:
+        """The batched sibling of ``get_next_state``: ``states`` int array [B, N, 2], ``actions`` int array [B] ->
+        next states int8 [B, N, 2].  One asynchronous upload from pinned memory, one ``pw_step`` launch, one download."""
+        st = np.ascontiguousarray(np.asarray(states), dtype=np.int8)
+        acts = np.ascontiguousarray(np.asarray(actions), dtype=np.uint8)
+        if st.ndim != 3 or st.shape[1:] != (self.num_movables, 2) or acts.shape != (st.shape[0],):
+            raise ValueError(f"states must have shape [B, {self.num_movables}, 2] and actions shape [B]")
+        if acts.size and acts.max() > 3:
+            raise ValueError("action must be one of 0 (L), 1 (R), 2 (U), 3 (D)")
+        B = st.shape[0]
+        if B == 0:
+            return np.zeros((0, self.num_movables, 2), np.int8)
         eng = self._engine()
-        b = self._state_bufs(eng)
-        self._upload(eng, state)
-        b["act"].fill_(int(action))
-        eng.step(b["pid"], b["act"], b["pos"], b["steps"], b["reward"], b["dgoals"], b["terminated"], b["truncated"])
-        return self._download(eng)
+        if self._batch is None or self._batch["pos"].shape[0] < B:
+            cap = max(B, 1024)
+            bufs = eng.alloc_state(cap)
+            bufs["pid"] = torch.zeros((cap,), dtype=torch.int32, device=eng.device)
+            bufs["act"] = torch.zeros((cap,), dtype=torch.uint8, device=eng.device)
+            bufs["pos_host"] = torch.zeros((cap, eng.np, 2), dtype=torch.int8).pin_memory()
+            bufs["act_host"] = torch.zeros((cap,), dtype=torch.uint8).pin_memory()
+            self._batch = bufs
+        b = self._batch
+        ph, ah = b["pos_host"], b["act_host"]
+        ph[:B].zero_()
+        ph[:B, : self.num_movables] = torch.from_numpy(st)
+        ah[:B] = torch.from_numpy(acts)
+        pos, act = b["pos"][:B], b["act"][:B]
+        pos.copy_(ph[:B], non_blocking=True)
+        act.copy_(ah[:B], non_blocking=True)
+        eng.step(b["pid"][:B], act, pos, b["steps"][:B], b["reward"][:B], b["dgoals"][:B], b["terminated"][:B], b["truncated"][:B])
+        ph[:B].copy_(pos, non_blocking=True)
+        torch.cuda.current_stream(eng.device).synchronize()
+        return ph[:B, : self.num_movables].numpy().copy()
 
     def count_achieved_goals(self, state: State) -> int:
         """puzzle.py:396-407 (a host-side comparison of caller-owned tuples; the batched
@@ -222,16 +275,11 @@ class PushWorldPuzzle:
             return len(plan) == 0
         if not plan:
             return False
-        eng = self._engine()
-        b = self._state_bufs(eng)
-        self._upload(eng, self._initial_state)
-        # ONE launch for the whole plan: pw_rollout with the per-step terminated flags as history
-        acts = torch.tensor(plan, dtype=torch.uint8).view(len(plan), 1).to(eng.device)
-        term = torch.zeros((len(plan), 1), dtype=torch.uint8, device=eng.device)
-        eng.rollout(b["pid"], acts, b["pos"], b["steps"], b["reward"], b["dgoals"], b["terminated"], b["truncated"],
-                    None, term, None)
-        hist = term.cpu().numpy().reshape(-1)
-        return bool(hist[-1] == 1 and not hist[:-1].any())
+        if any(a not in (0, 1, 2, 3) for a in plan):
+            raise ValueError("action must be one of 0 (L), 1 (R), 2 (U), 3 (D)")
+        # ONE launch for the whole plan (pw_plan_states): the goal flag of every state it passes through
+        _, goals = self._engine().plan_states(0, bytes(plan))
+        return bool(goals[-1] == 1 and not goals[:-1].any())
 
     def expand4(self, states):
         """Planner successor expansion (cpp/include/search/best_first_search.h:76-78 calling
@@ -280,10 +328,22 @@ class PushWorldPuzzle:
 
     def render_plan(self, plan: Iterable[int], border_width: int = DEFAULT_BORDER_WIDTH,
                     pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL) -> List[np.ndarray]:
-        """puzzle.py:471-506."""
-        state = self._initial_state
-        images = [self.render(state, border_width, pixels_per_cell)]
-        for action in plan:
-            state = self.get_next_state(state, action)
-            images.append(self.render(state, border_width, pixels_per_cell))
-        return images
+        """puzzle.py:471-506: one ``pw_plan_states`` launch leaves every state of the plan in a device buffer, ONE batched
+        ``pw_render`` draws them all, one copy brings the images to the host."""
+        if border_width < 1:
+            raise ValueError("border_width must be >= 1")
+        if pixels_per_cell < 1 + 2 * border_width:
+            raise ValueError("pixels_per_cell must be >= 1 + 2*border_width")
+        plan = [int(a) for a in plan]
+        if any(a not in (0, 1, 2, 3) for a in plan):
+            raise ValueError("action must be one of 0 (L), 1 (R), 2 (U), 3 (D)")
+        eng = self._engine(pixels_per_cell, border_width, _capi.OBS_U8)
+        n = len(plan) + 1
+        dev_states = torch.zeros((n, eng.np, 2), dtype=torch.int8, device=eng.device)
+        torch.cuda.current_stream(eng.device).synchronize()  # (the plan kernel runs on the engine's own stream)
+        eng.plan_states(0, bytes(plan), dev_states=dev_states)
+        pid = torch.zeros((n,), dtype=torch.int32, device=eng.device)
+        storage, view = eng.alloc_obs(n)
+        eng.render(pid, dev_states, storage)
+        images = view.cpu().numpy()
+        return [images[i] for i in range(n)]

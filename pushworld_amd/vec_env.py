@@ -84,8 +84,9 @@ class VecPushWorld:
         self.num_puzzles = len(self.pset)
         ph, pw = pad_cells if pad_cells is not None else (0, 0)
         dtype = _capi.OBS_F32 if observation == "float32" else _capi.OBS_U8
+        # (max_batch: the engine's per-environment scratch is sized here, once -- no step / render call allocates later)
         self.engine = _capi.Engine(self.pset, max_steps, pixels_per_cell, border_width, dtype, ph, pw,
-                                   options=engine_options)
+                                   options=engine_options, max_batch=int(num_envs) if observation is not None else 0)
         self.device = self.engine.device
         self.num_envs = int(num_envs)
         self.observation = observation
@@ -101,10 +102,13 @@ class VecPushWorld:
             if ids.shape != (self.num_envs,) or ids.min() < 0 or ids.max() >= self.num_puzzles:
                 raise ValueError("puzzle_ids must be [num_envs] indices into the puzzle pool")
         self.puzzle_id = torch.as_tensor(ids, dtype=torch.int32).to(self.device)
-        if "step_block_order" not in (engine_options or {}) and self.num_envs >= 4096:
+        if "step_block_order" not in (engine_options or {}) and self.num_envs >= 4096 and not resample:
             # A launch lasts as long as its slowest wavefronts: when the expensive puzzles (many movables) sit at the
             # END of the batch (pools sorted by level), let the step kernel start there and the cheap ones fill the tail.
-            n_mov = np.frombuffer(self.pset.headers(), np.uint8).reshape(-1, 320)[:, 6].astype(np.float64)  # PwPuzzleHeader::N
+            # (Only for a fixed assignment: with `resample` the puzzles of the batch change every episode.)
+            hdr = np.frombuffer(self.pset.headers(), np.uint8)
+            assert hdr.size == _capi.PUZZLE_HEADER_BYTES * self.num_puzzles, "PwPuzzleHeader layout changed (csrc/pw_format.h)"
+            n_mov = hdr.reshape(-1, _capi.PUZZLE_HEADER_BYTES)[:, _capi.PUZZLE_HEADER_N_OFFSET].astype(np.float64)
             cost = n_mov[np.asarray(ids, dtype=np.int64)]
             q = max(1, self.num_envs // 4)
             if cost[-q:].mean() > 1.15 * cost[:q].mean():
@@ -123,14 +127,21 @@ class VecPushWorld:
             nbytes = self.num_envs * self.engine.obs_stride
             if tune is None:
                 tune = nbytes >= (256 << 20)
-            if tune and tune_allocations is None:  # as many as fit into a third of the device memory, at most 32
-                # (of the TOTAL memory: torch.cuda.mem_get_info() was seen returning 0 free bytes on these boxes;
-                # the library chooses among the candidates there are when memory runs out)
+            if tune and tune_allocations is None:
+                # At most 32 candidates, all alive at once while the choice is made: within a third of the device memory
+                # AND within what is free right now (a co-resident model or torch's own allocator must not be pushed into
+                # OOM during the constructor); torch.cuda.mem_get_info() was seen returning 0 free bytes on these boxes:
+                # then a small count, and the library stops at the candidates there are when memory runs out.
+                # (On a box whose allocations are mostly of the slow class -- one in six to thirteen fast,
+                # profiles/r03_bench_final7.json: the 14th candidate was the first fast one -- twelve candidates miss one
+                # time in three; a candidate costs ~40 ms and goes back to the device.)
                 total = torch.cuda.get_device_properties(self.device).total_memory
-                # (on a box whose allocations are mostly of the slow class -- one in six to thirteen fast,
-                # profiles/r03_trace_bench_line.json, r03_bench_final7.json: the 14th candidate was the first fast one -- twelve
-                # candidates miss one time in three; a candidate costs ~40 ms and goes back to the device)
-                tune_allocations = min(32, max(1, int(total // 3 // nbytes)))
+                try:
+                    free = int(torch.cuda.mem_get_info(self.device)[0])
+                except Exception:  # noqa: BLE001
+                    free = 0
+                budget = min(total // 3, free // 2) if free > 0 else 4 * nbytes
+                tune_allocations = min(32, max(1, int(budget // nbytes)))
             owned = False
             if tune and tune_allocations:
                 # library-owned buffer: candidates are tuned on the initial states (reset() draws them again)
@@ -164,6 +175,18 @@ class VecPushWorld:
             self.sample_table = torch.as_tensor(tab, dtype=torch.int32).to(self.device)
         # episode number of every environment (uint32 counter bits in an int32 tensor)
         self.episode = torch.zeros((self.num_envs,), dtype=torch.int32, device=self.device)
+        # pre-marshalled step entry points (the state tensors never move: their pointers are converted once)
+        self._act_shape = (self.num_envs,)
+        self._call_step = self.engine.bind_step(self.puzzle_id, self.pos, self.steps, self.reward, self.dgoals,
+                                                self.terminated, self.truncated, self.flags)
+        self._call_step_render = self._call_step_delta = None
+        if self.obs is not None:
+            self._call_step_render = self.engine.bind_step_render(
+                self.puzzle_id, self.pos, self.steps, self.reward, self.dgoals, self.terminated, self.truncated,
+                self._obs_storage, self.flags)
+            self._call_step_delta = self.engine.bind_step_render(
+                self.puzzle_id, self.pos, self.steps, self.reward, self.dgoals, self.terminated, self.truncated,
+                self._obs_storage, self.flags, delta=True)
 
     # --------------------------------------------------------------------------------
     @property
@@ -202,25 +225,33 @@ class VecPushWorld:
         """
         if not self._has_reset:
             raise RuntimeError("reset() must be called before step() can be called.")
-        if actions.dtype != torch.uint8 or actions.device != self.device or actions.shape != (self.num_envs,):
-            raise ValueError("actions must be a uint8 tensor of shape [num_envs] on the engine's device")
+        if actions.dtype != torch.uint8 or actions.device != self.device or actions.shape != self._act_shape \
+                or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous uint8 tensor of shape [num_envs] on the engine's device")
         if self.resample and self.flags & _capi.STEP_AUTORESET:
             # finished environments draw the puzzle their autoreset (inside this step) starts from
             self.engine.resample(self.puzzle_id, self.episode, self.seed, self.terminated, self.truncated,
                                  self.sample_table)
-        if self.obs is not None and self.incremental and self._obs_current:
-            self.engine.step_render_delta(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
-                                          self.terminated, self.truncated, self._obs_storage, self.flags)
-        elif self.obs is not None and self.fused:
-            self.engine.step_render(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
-                                    self.terminated, self.truncated, self._obs_storage, self.flags)
+        if self.obs is None:
+            self._call_step(actions.data_ptr())  # one ctypes call with ready arguments: the launch is host bound
+            return None, self.reward, self.terminated, self.truncated
+        if self.incremental and self._obs_current:
+            self._call_step_delta(actions.data_ptr())
+        elif self.fused:
+            self._call_step_render(actions.data_ptr())
         else:
-            self.engine.step(self.puzzle_id, actions, self.pos, self.steps, self.reward, self.dgoals,
-                             self.terminated, self.truncated, self.flags)
-            if self.obs is not None:
-                self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
-        self._obs_current = self.obs is not None
+            self._call_step(actions.data_ptr())
+            self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
+        self._obs_current = True
         return self.obs, self.reward, self.terminated, self.truncated
+
+    def counters(self) -> dict:
+        """Device-side throughput counters of this environment's engine (``pw_counters``): env_steps, episodes_ended,
+        episodes_solved, bad_actions since construction (or ``counters_reset``).  Synchronises the stream."""
+        return self.engine.counters()
+
+    def counters_reset(self) -> None:
+        self.engine.counters_reset()
 
     def rollout(self, actions: torch.Tensor, history: bool = False):
         """T steps in ONE launch without observations (``pw_rollout``): ``actions`` is a uint8 tensor

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
-    assert lib.pw_abi_version() == 3
+    assert lib.pw_abi_version() == 4
 
 
 def test_parse_products_match_reference(golden):
