@@ -26,11 +26,15 @@ one 14 ms window is inside the +-3 % spread between observation-buffer allocatio
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects: ``roofline`` for
 the dominant kernel (render; HBM bound), timed live by HIP events the library records around that launch on
 the launch stream (``PW_OPT_PROFILE_RENDER``), and ``cpu_baseline`` = the C restatement of the reference
-algorithm (oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample, with 1 thread and
-with all threads, plus the pure-Python restatement of the reference environment (the reference's own Python
-env cannot travel to the GPU box) on 1 core and on P processes.  Non-headline extras of the c3 line (``--no-extras`` drops
-them): ``incremental_render`` (the persistent observation buffer maintained by pw_step_render_delta), ``state_only_rollout``
-(64 steps per launch) and ``expand4`` (config C5: pw_expand4 on a ~1 M-state frontier of `Four Pistons`).
+algorithm (oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample (pinned OpenMP threads, best
+of three samples, all three reported), with 1 thread and with all threads, plus the pure-Python restatement of the
+reference environment (the reference's own Python env cannot travel to the GPU box) on 1 core and on P processes.
+``counters`` is the vector the step kernels keep on the device (pw_counters), summed over ranks by the job's one
+all_reduce.  ``configs`` (N = 1, c3 line; ``--no-configs`` drops it) puts every other BASELINE.json configuration on the
+same clock (tools/config_suite.py): C1, C2, C3 float32 ppc 3 / ppc 20, C4 state-only + uint8, C5 on three puzzles, each
+with its dominant kernel's launch time, roofline fraction, PMC traffic record and its own CPU baseline.  Non-headline
+extras (``--no-extras`` drops them): ``incremental_render`` (the persistent observation buffer maintained by
+pw_step_render_delta) and ``state_only_rollout`` (64 steps per launch).
 """
 import argparse
 import json
@@ -42,6 +46,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU baselines' OpenMP threads stay where they start (one place per core): libgomp reads these when it is loaded,
+# which `import torch` does -- so before it
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -85,105 +93,27 @@ def device_report(device_index):
     return rep
 
 
-def cpu_model():
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
 # ------------------------------------------------------------------------------------------ CPU baselines
-def cpu_baseline(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw, target_seconds=10.0):
-    """The oracle's C port on the host cores, same puzzle mix / action distribution / render settings, bounded
-    sample: all OpenMP threads (the headline ``value``) and one thread."""
-    from oracle import c_oracle
+def cpu_baseline(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw, target_seconds=3.0):
+    """The oracle's C port on the host cores (tools/cpu_baselines.py: same puzzle mix / action distribution / render
+    settings, bounded sample, pinned OpenMP threads, best of three samples -- all three values are in the line)."""
+    from tools import cpu_baselines as cb
 
-    B = min(4096, len(ids_full))
-    stride = max(1, len(ids_full) // B)
-    ids_sample = np.asarray(ids_full[::stride][:B], dtype=np.int64)
-    used = np.unique(ids_sample)  # only the puzzles the sample touches are compiled (c4: <= 4096 of 14 223)
-    remap = {int(p): i for i, p in enumerate(used)}
-    puzzles = [c_oracle.COraclePuzzle(texts[int(p)]) for p in used]
-    ids = np.asarray([remap[int(p)] for p in ids_sample], dtype=np.int32)
-    B = len(ids)
-    rng = np.random.default_rng(12345)
-
-    def timed(T, threads):
-        acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
-        t0 = time.perf_counter()
-        _, used_threads = c_oracle.rollout(puzzles, ids, acts, max_steps, render, pad_h, pad_w, ppc, bw, threads=threads)
-        dt = time.perf_counter() - t0
-        return B * T / dt, used_threads, dt
-
-    # An explicit thread count (torch.distributed.run exports OMP_NUM_THREADS=1 to every rank): the faster of "all
-    # hardware threads this process may use" and half of them (one per physical core on an SMT-2 host).
-    try:
-        hw = len(os.sched_getaffinity(0))
-    except AttributeError:
-        hw = os.cpu_count() or 1
-    def calibrated_rate(threads):
-        """rate from a run long enough (>= 0.3 s) that thread start-up does not dominate"""
-        timed(2, threads)  # warm (thread pool, caches)
-        T = 16
-        while True:
-            rate, used, dt = timed(T, threads)
-            if dt >= 0.3 or T >= 8192:
-                return rate, used
-            T *= 4
-
-    best = None
-    for cand in sorted({hw, max(1, hw // 2)}):
-        rate = calibrated_rate(cand)[0]
-        if best is None or rate > best[1]:
-            best = (cand, rate)
-    all_threads = best[0]
-    out = {}
-    for label, threads, budget in (("all", all_threads, target_seconds), ("one", 1, target_seconds * 0.4)):
-        rate, used_threads = calibrated_rate(threads)
-        T2 = int(max(4, min(65536, budget * rate / B)))
-        rate, used_threads, dt = timed(T2, threads)
-        out[label] = (rate, used_threads, T2, dt)
-    what = f"step + padded uint8 render ppc={ppc}" if render else "step only (no observation)"
-    rate, threads, T2, dt = out["all"]
-    r1, _, T1, dt1 = out["one"]
-    return {
-        "value": rate,
-        "unit": "env-steps/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"{B} envs (same puzzle mix) x {T2} steps, {what}, OpenMP over envs, {dt:.1f} s",
-        "one_thread": {"value": r1, "cores": 1, "sample": f"{B} envs x {T1} steps, {dt1:.1f} s"},
-        "host_cpus": os.cpu_count(),
-        "cpu_model": cpu_model(),
-    }
+    out = cb.port_rollout_rate(texts, ids_full, max_steps, 1 if render else 0, pad_h, pad_w, ppc, bw, seconds=target_seconds)
+    out["host_cpus"] = os.cpu_count()
+    out["cpu_model"] = cb.cpu_model()
+    return out
 
 
 def python_env_baseline(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw, target_seconds=3.0):
-    """The pure-Python restatement of the reference environment (oracle/pw_oracle.py: hash-set collision
-    tables, per-cell painter, /255 + np.pad -- the closest thing to the reference's own CPU Python env that
-    can travel to this box): one process, and P independent worker processes."""
-    from oracle import py_bench
+    """The pure-Python restatement of the reference environment on 1 core and on P worker processes."""
+    from tools import cpu_baselines as cb
 
     rng = np.random.default_rng(777)
     used = np.unique(np.asarray(ids_full))
     picks = [int(p) for p in rng.choice(used, size=min(4, len(used)), replace=False)]
-    job = dict(texts=[texts[p] for p in picks], max_steps=max_steps, render=bool(render), pad_h=pad_h, pad_w=pad_w,
-               ppc=ppc, bw=bw, seconds=target_seconds)
-    one = py_bench.run(dict(job, seed=777))
-    procs = min(os.cpu_count() or 1, 128)
-    many = py_bench.run_many(job, procs)
-    what = f"step + padded uint8 render ppc={ppc}" if render else "step only"
-    return {
-        "value": one["steps"] / one["seconds"], "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
-        "sample": f"{len(picks)} puzzles of the mix x {one['steps'] // len(picks)} steps, {what}, {one['seconds']:.1f} s; "
-                  f"collision-table construction took {one['build_seconds']:.1f} s (not included)",
-        "processes": {"value": many["steps_per_s"], "cores": many["processes"],
-                      "sample": f"{many['processes']} worker processes x {target_seconds:.0f} s, same job each"},
-    }
+    return cb.python_env_rate([texts[p] for p in picks], max_steps, render, pad_h, pad_w, ppc, bw, seconds=target_seconds,
+                              processes=min(os.cpu_count() or 1, 128))
 
 
 # ------------------------------------------------------------------------------------------ workloads
@@ -275,9 +205,14 @@ def main():
                     help="default: uint8 for c3, none (state only) for c4")
     ap.add_argument("--max-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0,
-                    help="CPU work of the all-threads C-port sample (the other CPU samples scale with it)")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0,
+                    help="CPU work of ONE all-threads C-port sample (three are taken, the best is the value; the other CPU "
+                         "samples scale with it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the incremental-render / rollout extras")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` object (every other BASELINE.json configuration on the clock; N = 1, c3 line only)")
+    ap.add_argument("--configs-only", default=None,
+                    help="comma-separated prefixes of the configurations to run (C1,C2,C3_f32_ppc3,C3_f32_ppc20,C4_state,C4_u8,C5)")
     ap.add_argument("--shared-device", action="store_true",
                     help="plumbing test on a 1-GPU box: all ranks on cuda:0, gloo for the counter reduction "
                          "(RCCL refuses two ranks on one device)")
@@ -355,6 +290,7 @@ def main():
     actions = torch.randint(0, 4, (n_act, B), generator=gen, device=dev, dtype=torch.uint8)
 
     vec.reset()
+    vec.counters_reset()  # the device-side throughput counters (pw_counters) count the timed windows only
 
     step_events = []
 
@@ -398,6 +334,8 @@ def main():
     if obs_mode is not None:
         eng.profile_render(K * M)
 
+    torch.cuda.synchronize()
+    vec.counters_reset()
     windows = []
     t_next = Wm
     for _ in range(M):
@@ -416,11 +354,15 @@ def main():
     # the collectives of the whole job: SUM of the step counters, MAX of every window (a few bytes), and the
     # per-rank medians gathered for the report
     own_median = float(np.median(windows))
-    counters, _ = reduce_counters({"env_steps": B * K, "ranks": 1}, own_median, device=red_dev)
+    # THE collective of the job: SUM over ranks of the counters the step kernels kept on the device
+    dev_counters = vec.counters()
+    counters, _ = reduce_counters(dict(dev_counters, ranks=1), own_median, device=red_dev)
     win_max = reduce_max(windows, device=red_dev)  # per window: the slowest rank
     per_rank = gather_floats(own_median, device=red_dev)
     if counters["ranks"] != world:
         raise SystemExit(f"bench.py: only {counters['ranks']} of {world} ranks reported")
+    if counters["env_steps"] != B * K * M * world or dev_counters["env_steps"] != B * K * M:
+        raise SystemExit(f"bench.py: the device counted {counters['env_steps']} env-steps, the loop issued {B * K * M * world}")
     # every rank's dominant-kernel time and what its allocator found (a few floats per rank)
     if obs_mode is not None:
         own_ms = np.array(eng.profile_read(), dtype=np.float64)
@@ -436,7 +378,7 @@ def main():
                     -1.0 if numa_node is None else float(numa_node)]
     rank_rows = gather_vectors(rank_row, device=red_dev)
     elapsed = float(np.median(win_max))
-    total_steps = counters["env_steps"]  # per window, all ranks
+    total_steps = counters["env_steps"] // M  # per window, all ranks (device-counted)
 
     if dist is not None:
         dist.barrier()
@@ -504,7 +446,13 @@ def main():
             "min_ms_per_step": 1000.0 * min(win_max) / K,
             "max_ms_per_step": 1000.0 * max(win_max) / K,
             "per_rank_median_ms_per_step": [1000.0 * w / K for w in per_rank],
+            # the same job read rank by rank: every rank's own median rate, summed -- next to the headline (per window the
+            # SLOWEST rank) it shows whether a gap to N x the single-GPU value is one slow rank or all of them
+            "sum_of_per_rank_median_rates": float(sum(B * K / w for w in per_rank)),
         },
+        "counters": {k: int(v) for k, v in counters.items() if k != "ranks"},
+        "counters_source": "pw_counters: kept on the device by the step kernels (one atomic per wavefront), summed over ranks by "
+                           "the job's one all_reduce; env_steps == envs x steps x windows x ranks is asserted",
     }
     out["timing"]["numa_node_per_rank"] = [None if r[6] < 0 else int(r[6]) for r in rank_rows]
     if obs_mode is not None:
@@ -580,13 +528,17 @@ def main():
         }
         out["config"]["algorithmic_bytes_per_env_step"] = state_bytes
 
-    # Scaling efficiency against the N = 1 run of the same workload: value / (N x the N = 1 value).  An N = 1 run
-    # leaves its value in profiles/bench_n1_latest.json (the driver runs N = 1, 2, 4, 8 back to back from one
-    # directory; otherwise the committed record of the last session is used and says so).
-    sig = {"config": args.config, "obs": args.obs, "envs_per_gpu": B, "ppc": args.ppc, "bw": args.bw, "max_steps": args.max_steps}
-    n1_path = os.path.join(ROOT, "profiles", "bench_n1_latest.json")
+    # Scaling efficiency against the N = 1 run of the same workload ON THIS HOST WITH THIS KERNEL SOURCE: value / (N x the
+    # N = 1 value).  An N = 1 run leaves its value in gpurun_out/bench_n1_latest.json (untracked scratch; the driver runs
+    # N = 1, 2, 4, 8 back to back from one directory); a record of other kernels, another host or another day is refused,
+    # not labelled.
+    from tools.config_suite import csrc_sha
+    sig = {"config": args.config, "obs": args.obs, "envs_per_gpu": B, "ppc": args.ppc, "bw": args.bw, "max_steps": args.max_steps,
+           "csrc_sha16": csrc_sha()}
+    n1_path = os.path.join(ROOT, "gpurun_out", "bench_n1_latest.json")
     if world == 1 and not args.shared_device:
         try:
+            os.makedirs(os.path.dirname(n1_path), exist_ok=True)
             with open(n1_path, "w") as f:
                 json.dump({"signature": sig, "value": out["value"], "ms_per_step": out["ms_per_step"], "unix_time": time.time(),
                            "host": socket.gethostname(), "git_head": git_head()}, f, indent=1)
@@ -596,15 +548,17 @@ def main():
         try:
             with open(n1_path) as f:
                 rec = json.load(f)
-            if rec.get("signature") == sig and rec.get("value", 0) > 0:
-                same = rec.get("host") == socket.gethostname() and time.time() - rec.get("unix_time", 0) < 6 * 3600
+            fresh = rec.get("host") == socket.gethostname() and time.time() - rec.get("unix_time", 0) < 6 * 3600
+            if rec.get("signature") == sig and rec.get("value", 0) > 0 and fresh:
                 out["scaling_efficiency"] = {
                     "value": out["value"] / (world * rec["value"]), "n1_value": rec["value"],
-                    "n1_source": "profiles/bench_n1_latest.json: " + ("N = 1 run on this host %d s ago" % (time.time() - rec["unix_time"])
-                                                                      if same else "committed record of an earlier session (head %s)" % rec.get("git_head")),
+                    "n1_source": "gpurun_out/bench_n1_latest.json: N = 1 run on this host %d s ago, same kernel source" % (time.time() - rec["unix_time"]),
+                    "sum_of_per_rank_rates_over_n_x_n1": out["timing"]["sum_of_per_rank_median_rates"] / (world * rec["value"]),
                 }
+            else:
+                out["scaling_efficiency"] = {"value": None, "why": "the N = 1 record is stale (other kernel source, workload, host, or older than 6 h): refused"}
         except (OSError, ValueError):
-            pass
+            out["scaling_efficiency"] = {"value": None, "why": "no N = 1 run of this workload on this host yet (run bench.py --gpus 1 first)"}
 
     if not args.no_extras:
         # extra (not the headline): the same loop with the observation buffer maintained incrementally
@@ -645,46 +599,11 @@ def main():
                                           "steps_per_launch": Tn, "envs": B, "n_gpus": 1}
         except Exception as exc:  # noqa: BLE001
             out["state_only_rollout"] = {"error": repr(exc)}
-        # extra (not the headline): config C5 of BASELINE.json -- pw_expand4 on a frontier of ~1 M distinct states of
-        # `Four Pistons` (N = 12) collected by the GPU breadth-first search; 20 N + 20 algorithmic bytes per parent
-        if args.config == "c3":
-            try:
-                from pushworld_amd.puzzle import PushWorldPuzzle
-                from pushworld_amd.search import BreadthFirstSearch
-
-                pz = PushWorldPuzzle(os.path.join(ROOT, "pushworld_amd", "data", "puzzles", "level4", "Four Pistons.pwp"), order="cpp")
-                bfs = BreadthFirstSearch(pz, max_states=3_000_000)
-                bfs.begin()
-                while bfs.total_states < 1_000_000 and not bfs.exhausted:
-                    bfs.expand()
-                F = min(bfs.total_states, 1_000_000)
-                xy = bfs.states(0, F)
-                bfs.close()
-                st = torch.as_tensor((xy[:, :, 0].astype(np.int64) * 10000 + xy[:, :, 1]).astype(np.int32)).to(dev)
-                N = st.shape[1]
-                succ = torch.empty((F, 4, N), dtype=torch.int32, device=dev)
-                moved = torch.empty((F, 4), dtype=torch.int32, device=dev)
-                goal = torch.empty((F, 4), dtype=torch.uint8, device=dev)
-                peng = pz._engine()
-                peng.expand4(0, st, succ, moved, goal)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    peng.expand4(0, st, succ, moved, goal)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 10
-                out["expand4"] = {"parents_per_s": F / (ms * 1e-3), "states": int(F), "movables": int(N), "puzzle": "level4/Four Pistons",
-                                  "ms": ms, "algorithmic_gbs": F * (20 * N + 20) / (ms * 1e-3) / 1e9,
-                                  "frac_of_hbm_peak": F * (20 * N + 20) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "note": "config C5 (pw_expand4, one lane per state); bit-exact vs the C oracle on such frontiers in "
-                                          "tests/test_gpu_expand.py; not the headline value"}
-            except Exception as exc:  # noqa: BLE001
-                out["expand4"] = {"error": repr(exc)}
     if not args.no_cpu_baseline:
         # rank 0's host cores, also for N > 1 (the other ranks have finished; their processes are idle or gone)
         fh, fw = eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc
+        torch.cuda.synchronize()
+        time.sleep(2.0)  # the host has been feeding launches: let it settle before the CPU samples
         try:
             out["cpu_baseline"] = cpu_baseline(wl["texts"], wl["ids"], args.max_steps, obs_mode is not None, fh, fw,
                                                args.ppc, args.bw, target_seconds=args.cpu_seconds)
@@ -693,6 +612,23 @@ def main():
                 target_seconds=max(0.5, 0.3 * args.cpu_seconds))
         except Exception as exc:  # noqa: BLE001
             out["cpu_baseline"] = {"error": repr(exc)}
+    # every other BASELINE.json configuration on the same clock (N = 1, default line only): C1, C2, C3 float32 ppc 3 / ppc 20,
+    # C4 state-only + uint8, C5 on three puzzles -- each with its kernel's roofline fraction and its own CPU baseline
+    if world == 1 and args.config == "c3" and not args.no_configs and not args.shared_device:
+        del vec, eng
+        wl.clear()
+        torch.cuda.empty_cache()
+        from tools import config_suite
+
+        t_cfg = time.perf_counter()
+        out["configs"] = config_suite.run_all(args.configs_only.split(",") if args.configs_only else None,
+                                              cpu=not args.no_cpu_baseline,
+                                              log=lambda msg: print("bench.py: " + msg, file=sys.stderr, flush=True))
+        out["configs"]["C3_u8_ppc3"] = {"see": "the top-level fields of this line (the headline)", "value": out["value"],
+                                        "unit": out["unit"], "kernel": out["roofline"]["kernel"], "frac": out["roofline"]["frac"],
+                                        "avg_launch_ms": out["roofline"]["avg_launch_ms"], "traffic": out["roofline"]["traffic"],
+                                        "algorithmic_bytes_per_unit": out["roofline"]["algorithmic_bytes_per_launch"] // B}
+        out["configs_wall_s"] = time.perf_counter() - t_cfg
     print(json.dumps(out), flush=True)
 
 

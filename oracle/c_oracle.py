@@ -185,14 +185,16 @@ def expand4_batch(puzzle, states):
 
 
 def rollout(puzzles, puzzle_ids, actions, max_steps, render, pad_h, pad_w, ppc, bw, threads=0):
-    """Batched CPU baseline: ``actions`` uint8 [T][B]; ``threads`` <= 0 = all OpenMP threads.
+    """Batched CPU baseline: ``actions`` uint8 [T][B]; ``threads`` <= 0 = all OpenMP threads; ``render`` False / 0 no
+    observation, True / 1 / "u8" the padded uint8 observation every step, 2 / "f32" the float32 one.
     Returns (checksum, threads used)."""
+    render = {"u8": 1, "f32": 2, "uint8": 1, "float32": 2}.get(render, render) if isinstance(render, str) else int(render)
     handles = (c_void_p * len(puzzles))(*[p.handle for p in puzzles])
     pid = np.ascontiguousarray(np.asarray(puzzle_ids, dtype=np.int32))
     acts = np.ascontiguousarray(np.asarray(actions, dtype=np.uint8))
     T, B = acts.shape
     used = c_int(0)
     chk = lib().or_rollout(handles, pid.ctypes.data_as(POINTER(c_int32)), B, T,
-                           acts.ctypes.data_as(POINTER(c_uint8)), int(-1 if max_steps is None else max_steps), int(bool(render)),
+                           acts.ctypes.data_as(POINTER(c_uint8)), int(-1 if max_steps is None else max_steps), int(render),
                            pad_h, pad_w, ppc, bw, int(threads), ctypes.byref(used))
     return int(chk), used.value

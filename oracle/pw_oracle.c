@@ -337,8 +337,8 @@ void or_observation_f32(const OrPuzzle* p, const int* state, int pad_h, int pad_
 /* ------------------------------------------------------------------ batched baseline driver
  * B environments (env b uses puzzles[pid[b]]), T steps of pre-generated actions [T][B], with
  * the reference's reset-on-done handled like the GPU bench (next-step autoreset).  When
- * `render` != 0 every step also renders the padded uint8 observation into a per-thread
- * buffer.  Returns a checksum so the work cannot be optimised away.  OpenMP over envs. */
+ * `render` != 0 every step also renders the padded observation into a per-thread buffer (1: uint8,
+ * 2: float32 = uint8 / 255 as env_utils.py:65-72).  Returns a checksum so the work cannot be optimised away.  OpenMP over envs. */
 uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, const uint8_t* actions,
                     int max_steps, int render, int pad_h, int pad_w, int ppc, int bw, int num_threads,
                     int* threads_used) {
@@ -353,7 +353,7 @@ uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, 
     uint8_t* obs = NULL;
     uint8_t* scratch = NULL;
     if (render) {
-      obs = (uint8_t*)malloc((size_t)pad_h * pad_w * ppc * ppc * 3);
+      obs = (uint8_t*)malloc((size_t)pad_h * pad_w * ppc * ppc * 3 * (render == 2 ? sizeof(float) : 1));
       scratch = (uint8_t*)malloc((size_t)pad_h * pad_w * ppc * ppc * 3);
     }
 #pragma omp for schedule(dynamic, 16)
@@ -379,7 +379,10 @@ uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, 
           steps++;
           done = term || (max_steps >= 0 && steps >= max_steps);
         }
-        if (render) {
+        if (render == 2) {
+          or_observation_f32(p, state, pad_h, pad_w, ppc, bw, (float*)obs, scratch);
+          total += (uint64_t)(((float*)obs)[((size_t)pad_h * ppc / 2) * pad_w * ppc * 3 + (size_t)pad_w * ppc / 2 * 3] > 0.5f);
+        } else if (render) {
           or_observation_u8(p, state, pad_h, pad_w, ppc, bw, obs, scratch);
           total += obs[((size_t)pad_h * ppc / 2) * pad_w * ppc * 3 + (size_t)pad_w * ppc / 2 * 3];
         }

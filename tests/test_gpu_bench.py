@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-extras"]
+SMALL = ["--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-extras", "--no-configs"]
 
 
 def run_bench(*argv, timeout=600, extra_env=None):
@@ -59,6 +59,13 @@ def test_self_spawned_two_ranks_sum_their_counters():
     se = d["scaling_efficiency"]
     assert se["n1_value"] == pytest.approx(lines1[0]["value"]) and "on this host" in se["n1_source"]
     assert se["value"] == pytest.approx(d["value"] / (2 * lines1[0]["value"]))
+    # the counters the step kernels kept on the device, summed over both ranks by the one all_reduce of the job
+    c = d["counters"]
+    assert c["env_steps"] == 2 * 2048 * 3 * 2 and c["bad_actions"] == 0 and 0 <= c["episodes_solved"] <= c["episodes_ended"]
+    assert lines1[0]["counters"]["env_steps"] == 2048 * 3 * 2
+    # both statistics: per window the slowest rank (the headline) and every rank's own median rate, summed
+    assert d["timing"]["sum_of_per_rank_median_rates"] >= d["value"] * 0.999
+    assert se["sum_of_per_rank_rates_over_n_x_n1"] >= se["value"] * 0.999
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["one_thread"]["cores"] == 1 and cb["cpu_model"]
     assert cb["python_env"]["value"] > 0 and cb["python_env"]["processes"]["cores"] >= 1
@@ -84,6 +91,24 @@ def test_rccl_branch_runs_with_one_rank():
     assert len(d["roofline"]["per_rank_frac"]) == 1 and len(d["timing"]["per_rank_median_ms_per_step"]) == 1
 
 
+def test_eight_ranks_sharing_the_device_report_eight_rows():
+    """The N = 8 line's plumbing on the one GPU a test box has (``--shared-device``: gloo for the reductions): eight
+    per-rank rows everywhere the line reports per rank, eight NUMA entries, counters summed over eight ranks."""
+    proc, lines = run_bench("--gpus", "8", "--shared-device", "--steps", "2", "--warmup", "1", "--windows", "2", "--envs-per-gpu",
+                            "1024", "--no-extras", "--no-configs", "--no-cpu-baseline", timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 * 1024
+    assert len(d["roofline"]["per_rank_frac"]) == 8 and len(d["roofline"]["per_rank_avg_launch_ms"]) == 8
+    assert len(d["config"]["render_launch"]["per_rank"]) == 8
+    assert len(d["timing"]["per_rank_median_ms_per_step"]) == 8 and len(d["timing"]["numa_node_per_rank"]) == 8
+    assert d["counters"]["env_steps"] == 8 * 1024 * 2 * 2
+    # a stale or missing N = 1 record is refused, not labelled
+    se = d["scaling_efficiency"]
+    assert se["value"] is None or "on this host" in se["n1_source"]
+
+
 def test_more_ranks_than_devices_is_refused():
     """--gpus N with fewer than N devices must fail, not report n_gpus 1 (missing #1)."""
     import torch
@@ -107,15 +132,37 @@ def test_single_rank_line_has_the_contract_fields():
 
 
 def test_extras_of_the_line_run():
-    """The non-headline extras of the line (incremental render, state-only rollouts, config C5's pw_expand4 on a ~1 M-state
-    frontier) run and report numbers, not errors."""
-    proc, lines = run_bench("--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-cpu-baseline")
+    """The non-headline extras of the line (incremental render, state-only rollouts) run and report numbers, not errors."""
+    proc, lines = run_bench("--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-cpu-baseline",
+                            "--no-configs")
     assert proc.returncode == 0, proc.stderr[-2000:]
     d = lines[0]
-    for key in ("incremental_render", "state_only_rollout", "expand4"):
+    for key in ("incremental_render", "state_only_rollout"):
         assert key in d and "error" not in d[key], (key, d.get(key))
-    x = d["expand4"]
-    assert x["states"] >= 500_000 and x["movables"] == 12 and x["parents_per_s"] > 1e9 and 0 < x["frac_of_hbm_peak"] < 1
+
+
+def test_configs_object_of_the_line():
+    """``configs``: the other BASELINE.json configurations on the same clock (here C1, C2 and C5 on `2 Obstacle`; the driver's
+    run has all of them): value, kernel, launch time from the library's HIP events, roofline fraction, traffic field."""
+    proc, lines = run_bench("--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2048", "--no-cpu-baseline",
+                            "--no-extras", "--configs-only", "C1,C2,C5_2", timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    cfg = lines[0]["configs"]
+    assert set(cfg) == {"C1", "C2", "C5_2_obstacle", "C3_u8_ppc3"}, set(cfg)
+    for key in ("C1", "C2", "C5_2_obstacle"):
+        assert "error" not in cfg[key], cfg[key]
+    c1 = cfg["C1"]
+    assert c1["gym_step_with_render"]["value"] > 1e3 and c1["get_next_state_batch1"]["value"] > 1e4
+    assert c1["render_plan_100_steps"]["frames"] == 101 and c1["render_plan_100_steps"]["value"] < 100.0
+    c2 = cfg["C2"]
+    assert c2["unit"] == "env-steps/s" and c2["units_per_launch"] == 4096 and c2["algorithmic_bytes_per_unit"] == 38
+    assert c2["kernel"] == "pw_step_board_kernel" and 0 < c2["frac"] < 1 and c2["launches_timed"] == 500
+    assert c2["rollout_64_steps_per_launch"]["value"] > c2["value"]
+    assert c2["counters"]["env_steps"] > 0 and c2["counters"]["episodes_ended"] > 0
+    c5 = cfg["C5_2_obstacle"]
+    assert c5["unit"] == "parents/s" and c5["movables"] == 3 and c5["algorithmic_bytes_per_unit"] == 80
+    assert c5["states"] * c5["buffer_sets"] * 80 >= 600 << 20 and 0 < c5["frac"] < 1 and "traffic" in c5
+    assert cfg["C3_u8_ppc3"]["value"] == lines[0]["value"]
 
 
 @pytest.mark.parametrize("obs", ["none", "uint8"])

@@ -21,13 +21,19 @@ def test_product_sources_do_not_reference_the_oracle():
                     if pat.search(f.read()):
                         offenders.append(os.path.join(base, name))
     assert not offenders, offenders
-    with open(os.path.join(ROOT, "bench.py")) as f:
-        src = f.read()
-    # bench.py: the oracle only inside the two CPU-baseline functions
-    for m in re.finditer(r"^\s*from oracle import \w+", src, re.M):
-        head = src[:m.start()]
-        fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
-        assert fn in ("cpu_baseline", "python_env_baseline"), fn
+    # bench.py and the configuration suite reach the oracle only through tools/cpu_baselines.py (the cpu_baseline leg),
+    # imported inside the CPU-baseline code paths -- never at module level, never from the timed GPU loops
+    for rel in ("bench.py", os.path.join("tools", "config_suite.py")):
+        with open(os.path.join(ROOT, rel)) as f:
+            src = f.read()
+        assert not pat.search(src), rel
+        for m in re.finditer(r"^(\s*)from tools(\.cpu_baselines| import cpu_baselines)", src, re.M):
+            assert len(m.group(1)) >= 4, (rel, "cpu_baselines must be imported inside a function")
+            head = src[:m.start()]
+            fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
+            assert fn in ("cpu_baseline", "python_env_baseline", "run_c1", "run_c2", "run_c3", "run_c4", "run_c5"), (rel, fn)
+            if rel != "bench.py":  # ... and there behind the `if cpu:` switch
+                assert "if cpu:" in head[head.rindex("def " + fn):], (rel, fn)
 
 
 def test_missing_library_is_an_import_error_not_a_fallback(tmp_path):

@@ -31,7 +31,8 @@ def _worker(rank, world, port, total, out_dir):
     ids = (np.arange(total) * 68) // total
     mine = shard_puzzle_ids(ids, rank, world)
     lo, hi = shard_bounds(total, rank, world)
-    counters = {"env_steps": (hi - lo) * 10, "episodes": rank + 1, "first_id": int(mine[0]) if len(mine) else 0}
+    # the vector bench.py reduces: the four device-side counters of pw_counters (+ the rank count)
+    counters = {"env_steps": (hi - lo) * 10, "episodes_ended": rank + 1, "episodes_solved": rank, "bad_actions": 0, "ranks": 1}
     summed, elapsed = reduce_counters(counters, 0.5 + rank)
     # bench.py's per-window MAX over ranks and per-rank report
     wmax = reduce_max([1.0 + rank, 5.0 - rank])
@@ -43,7 +44,8 @@ def _worker(rank, world, port, total, out_dir):
     c4_mine = np.sort(shard_puzzle_ids(glob, rank, world))
     dist.barrier()
     np.save(os.path.join(out_dir, f"r{rank}.npy"),
-            np.array([summed["env_steps"], summed["episodes"], elapsed, lo, hi, len(mine), wmax[0], wmax[1],
+            np.array([summed["env_steps"], summed["episodes_ended"] + 10 * summed["episodes_solved"] + 100 * summed["ranks"]
+                      + 1000 * summed["bad_actions"], elapsed, lo, hi, len(mine), wmax[0], wmax[1],
                       per_rank[0], per_rank[1], float(glob.sum()), float(c4_mine.sum()), float(len(c4_mine)),
                       float((c4_mine < 14000).sum())], dtype=np.float64))
     dist.destroy_process_group()
@@ -55,7 +57,7 @@ def test_two_rank_gloo_sharding(tmp_path, total):
     mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
     rows = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
     for r, row in enumerate(rows):
-        assert row[0] == total * 10 and row[1] == 3 and row[2] == 1.5  # SUM, SUM, MAX over ranks
+        assert row[0] == total * 10 and row[1] == 3 + 10 * 1 + 100 * 2 and row[2] == 1.5  # SUM (5-vector), MAX over ranks
     assert rows[0][3] == 0 and rows[0][4] == rows[1][3] and rows[1][4] == total  # contiguous cover
     assert abs(rows[0][5] - rows[1][5]) <= 1
     for row in rows:

@@ -1,0 +1,148 @@
+"""CPU baselines of bench.py (the ``cpu_baseline`` leg: the only place besides tests/ and smoke() that runs anything under
+``oracle/``): the oracle's C port on this host's cores, on a bounded sample of the same workload.
+
+Stability: the OpenMP threads are pinned (``OMP_PROC_BIND=close OMP_PLACES=cores``, exported by bench.py
+before libgomp is loaded), every figure is the BEST of three samples, and all three values are reported."""
+import ctypes
+import os
+import time
+
+import numpy as np
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def hardware_threads():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def set_omp_threads(n):
+    """torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks; loops without a num_threads clause (the expansion
+    checker) take their thread count from here."""
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
+def port_rollout_rate(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw, seconds=3.0, samples=3, sample_envs=4096,
+                      with_one_thread=True):
+    """env-steps/s of the C port (``or_rollout``: OpenMP over environments, next-step autoreset) on ``sample_envs``
+    environments of the workload's puzzle mix.  ``render``: 0 state only, 1 / "u8" + padded uint8 observation, 2 / "f32"
+    + float32 observation.  Returns the ``cpu_baseline`` object."""
+    from oracle import c_oracle
+
+    B = min(sample_envs, len(ids_full))
+    stride = max(1, len(ids_full) // B)
+    ids_sample = np.asarray(ids_full[::stride][:B], dtype=np.int64)
+    used = np.unique(ids_sample)  # only the puzzles the sample touches are compiled
+    remap = {int(p): i for i, p in enumerate(used)}
+    puzzles = [c_oracle.COraclePuzzle(texts[int(p)]) for p in used]
+    ids = np.asarray([remap[int(p)] for p in ids_sample], dtype=np.int32)
+    B = len(ids)
+    rng = np.random.default_rng(12345)
+
+    def timed(T, threads):
+        acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
+        t0 = time.perf_counter()
+        _, used_threads = c_oracle.rollout(puzzles, ids, acts, max_steps, render, pad_h, pad_w, ppc, bw, threads=threads)
+        dt = time.perf_counter() - t0
+        return B * T / dt, used_threads, dt
+
+    def calibrated(threads):
+        """a rate from a run long enough (>= 0.25 s) that thread start-up does not dominate"""
+        T = 1
+        while True:
+            rate, used_threads, dt = timed(T, threads)
+            if dt >= 0.25 or T >= 16384:
+                return rate
+            T = max(T + 1, int(T * min(8.0, 0.3 / max(dt, 1e-4))))
+
+    hw = hardware_threads()
+    # all hardware threads this process may use, or one per physical core on an SMT-2 host: whichever is faster here
+    best_threads, best_rate = 1, 0.0
+    for cand in sorted({hw, max(1, hw // 2)}):
+        rate = calibrated(cand)
+        if rate > best_rate:
+            best_threads, best_rate = cand, rate
+
+    def best_of(threads, rate_guess, secs):
+        vals, T_used = [], 0
+        for _ in range(samples):
+            T2 = int(max(2, min(65536, secs * rate_guess / B)))
+            rate, used_threads, dt = timed(T2, threads)
+            vals.append(rate)
+            T_used = T2
+        return max(vals), vals, T_used
+
+    rate, vals, T2 = best_of(best_threads, best_rate, seconds)
+    what = {0: "step only (no observation)", 1: f"step + padded uint8 render ppc={ppc}",
+            2: f"step + padded float32 render ppc={ppc}"}[{"u8": 1, "f32": 2}.get(render, int(render)) if isinstance(render, str) else int(render)]
+    out = {
+        "value": rate, "unit": "env-steps/s", "cores": best_threads, "kind": "port",
+        "sample": f"{B} envs (same puzzle mix) x {T2} steps, {what}, OpenMP over envs (OMP_PROC_BIND="
+                  f"{os.environ.get('OMP_PROC_BIND', 'unset')} OMP_PLACES={os.environ.get('OMP_PLACES', 'unset')}), "
+                  f"best of {samples} samples of ~{seconds:.1f} s",
+        "samples": vals,
+    }
+    if with_one_thread:
+        r1 = calibrated(1)
+        rate1, vals1, T1 = best_of(1, r1, max(0.5, seconds * 0.4))
+        out["one_thread"] = {"value": rate1, "cores": 1, "sample": f"{B} envs x {T1} steps, best of {samples}", "samples": vals1}
+    return out
+
+
+def port_expand_rate(text, states, seconds=1.0, samples=3):
+    """parents/s of the C port's 4-action expansion (``or_expand4_batch``, OpenMP over states) on a sample of the same
+    frontier, C++ object order."""
+    from oracle import c_oracle
+
+    pz = c_oracle.COraclePuzzle(text, order="cpp")
+    threads = hardware_threads()
+    set_omp_threads(threads)
+    st = np.ascontiguousarray(states[: min(len(states), 262144)])
+    t0 = time.perf_counter()
+    c_oracle.expand4_batch(pz, st)
+    dt = time.perf_counter() - t0
+    reps = int(max(1, min(64, seconds / max(dt, 1e-4))))
+    vals = []
+    for _ in range(samples):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c_oracle.expand4_batch(pz, st)
+        vals.append(reps * len(st) / (time.perf_counter() - t0))
+    return {"value": max(vals), "unit": "parents/s", "cores": threads, "kind": "port",
+            "sample": f"{len(st)} states of the same frontier x {reps} passes, or_expand4_batch (OpenMP over states), best of {samples}",
+            "samples": vals}
+
+
+def python_env_rate(texts, max_steps, render, pad_h, pad_w, ppc, bw, seconds=2.0, processes=0):
+    """The pure-Python restatement of the reference environment (oracle/pw_oracle.py: hash-set collision tables, per-cell
+    painter, /255 + np.pad -- the closest thing to the reference's own CPU Python env that can travel to the GPU box), one
+    process; with ``processes`` > 0 also that many independent workers."""
+    from oracle import py_bench
+
+    job = dict(texts=list(texts), max_steps=max_steps, render=bool(render), pad_h=pad_h, pad_w=pad_w, ppc=ppc, bw=bw,
+               seconds=seconds)
+    one = py_bench.run(dict(job, seed=777))
+    what = f"step + padded uint8 render ppc={ppc}" if render else "step only"
+    out = {"value": one["steps"] / one["seconds"], "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
+           "sample": f"{len(texts)} puzzle(s) x {one['steps'] // max(1, len(texts))} steps, {what}, {one['seconds']:.1f} s; "
+                     f"collision-table construction took {one['build_seconds']:.1f} s (not included)"}
+    if processes > 0:
+        many = py_bench.run_many(job, processes)
+        out["processes"] = {"value": many["steps_per_s"], "cores": many["processes"],
+                            "sample": f"{many['processes']} worker processes x {seconds:.0f} s, same job each"}
+    return out
