@@ -46,10 +46,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the CPU baselines' OpenMP threads stay where they start (one place per core): libgomp reads these when it is loaded,
-# which `import torch` does -- so before it
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -266,6 +266,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       per environment on whole-grid uint64 boards -- registers only, no table lookups.
                                       0 (default) automatic, 2 never (the lane groups) */
 #define PW_OPT_STEP_BOARD_SET 23     /* read-only: 1 when the engine's set qualifies for PW_OPT_STEP_BOARDS */
+#define PW_OPT_EXPAND_LDS_TABLES 24  /* pw_expand4 with one lane per state: 0 (default) the kernel that keeps the puzzle's push tables in
+                                      LDS (pw_expand4_v2_kernel: 2 .. 16 movables, tables up to 48 KB, 16-byte aligned output
+                                      buffers) wherever it applies, 2 never (tables read from HBM through L1) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

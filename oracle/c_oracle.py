@@ -49,6 +49,8 @@ def lib():
         l.or_observe_batch.restype = None
         l.or_observe_batch.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_void_p, c_int, POINTER(c_int32), c_int,
                                        c_int, c_int, c_int, c_int, c_int, c_void_p]
+        l.or_set_thread_cpus.restype = None
+        l.or_set_thread_cpus.argtypes = [POINTER(c_int), c_int]
         l.or_expand4_batch.restype = None
         l.or_expand4_batch.argtypes = [c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]
         _lib = l
@@ -198,3 +200,10 @@ def rollout(puzzles, puzzle_ids, actions, max_steps, render, pad_h, pad_w, ppc, 
                            acts.ctypes.data_as(POINTER(c_uint8)), int(-1 if max_steps is None else max_steps), int(render),
                            pad_h, pad_w, ppc, bw, int(threads), ctypes.byref(used))
     return int(chk), used.value
+
+
+def set_thread_cpus(cpus):
+    """OpenMP thread t of the baseline runs (``rollout``, ``expand4_batch``) pins itself to ``cpus[t % len(cpus)]``; an empty
+    list switches the pinning off.  The calling thread is thread 0: save and restore its own mask around the runs."""
+    arr = (c_int * max(1, len(cpus)))(*cpus)
+    lib().or_set_thread_cpus(arr, len(cpus))

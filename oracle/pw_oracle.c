@@ -20,6 +20,10 @@
  *
  * Parsing is done by the Python oracle (oracle/pw_oracle.py), which hands over cell lists.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* sched_setaffinity, CPU_SET */
+#endif
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -339,6 +343,23 @@ void or_observation_f32(const OrPuzzle* p, const int* state, int pad_h, int pad_
  * the reference's reset-on-done handled like the GPU bench (next-step autoreset).  When
  * `render` != 0 every step also renders the padded observation into a per-thread buffer (1: uint8,
  * 2: float32 = uint8 / 255 as env_utils.py:65-72).  Returns a checksum so the work cannot be optimised away.  OpenMP over envs. */
+/* Thread placement of the baseline runs: OpenMP thread t of or_rollout pins itself to CPU cpus[t % n] (n = 0: no pinning).
+ * Set from Python (tools/cpu_baselines.py) with one hardware thread of every physical core first -- OMP_PROC_BIND in the
+ * environment would also bind the process's main thread, i.e. the thread that launches the GPU kernels. */
+static int g_cpus[1024];
+static int g_ncpus = 0;
+void or_set_thread_cpus(const int* cpus, int n) {
+  g_ncpus = n < 0 ? 0 : (n > 1024 ? 1024 : n);
+  for (int i = 0; i < g_ncpus; i++) g_cpus[i] = cpus[i];
+}
+static void or_pin_self(int tid) {
+  if (g_ncpus <= 0) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  CPU_SET(g_cpus[tid % g_ncpus], &set);
+  (void)sched_setaffinity(0, sizeof(set), &set);
+}
+
 uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, const uint8_t* actions,
                     int max_steps, int render, int pad_h, int pad_w, int ppc, int bw, int num_threads,
                     int* threads_used) {
@@ -350,6 +371,9 @@ uint64_t or_rollout(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, 
   if (threads_used) *threads_used = nthreads;
 #pragma omp parallel num_threads(nthreads) reduction(+ : total)
   {
+#ifdef _OPENMP
+    or_pin_self(omp_get_thread_num());
+#endif
     uint8_t* obs = NULL;
     uint8_t* scratch = NULL;
     if (render) {
@@ -472,7 +496,12 @@ void or_observe_batch(OrPuzzle* const* puzzles, const int32_t* pid, const int8_t
  * pushworld_puzzle.cc:446-457), goal uint8 [F][4] (satisfiesGoal of the successor, cc:462-469). */
 void or_expand4_batch(const OrPuzzle* p, const int32_t* states, int64_t F, int32_t* succ, uint32_t* moved, uint8_t* goal) {
   const int N = p->N;
-#pragma omp parallel for schedule(static, 1024)
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+  or_pin_self(omp_get_thread_num());
+#endif
+#pragma omp for schedule(static, 1024)
   for (int64_t f = 0; f < F; f++) {
     for (int a = 0; a < 4; a++) {
       int state[2 * MAXN];
@@ -486,5 +515,6 @@ void or_expand4_batch(const OrPuzzle* p, const int32_t* states, int64_t F, int32
       moved[o] = m;
       goal[o] = (uint8_t)(or_count_goals(p, state) == p->G);
     }
+  }
   }
 }

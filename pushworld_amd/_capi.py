@@ -181,6 +181,7 @@ OPTIONS = {
     "step_block_order": 20,    # 0 / "forward", 1 / "reverse": which end of the batch the step kernel starts with
     "step_boards": 22,         # sets of 8 x 8 puzzles, state only: 0 / "auto" whole-grid boards in registers, 2 / "never"
     "step_board_set": 23,      # read-only: the set qualifies
+    "expand_lds_tables": 24,   # pw_expand4, one lane per state: 0 / "auto" push tables in LDS where they fit, 2 / "never"
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2,
@@ -190,6 +191,7 @@ _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds":
 # names that mean different numbers for different options ("never" is a batch threshold for step_lane_batch)
 _OPTION_VALUES_BY_KEY = {"step_boards": {"auto": 0, "never": 2},
                          "step_narrow_groups": {"auto": 0, "always": 1, "never": 2},
+                         "expand_lds_tables": {"auto": 0, "never": 2},
                          "step_lds_tables": {"auto": 0, "always": 1, "never": 2}}
 
 

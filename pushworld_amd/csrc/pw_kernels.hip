@@ -61,11 +61,19 @@ struct PwOvlDir {
 // four actions (pw_expand4_lane_kernel).  32-bit words, 8 nibbles each, addressed from PwEngine::d_ovl.
 //   pair table (i, j), R2 = 2 max_h + 1 rows of RW words:  nibble (rx + w_i) of row (ry + h_i), i at (rx, ry) relative to j
 //   wall table j, Hs = H + 2 rows of WW words:             nibble (x + 1) of row (y + 1)
+//   byte pair table (i, j), R2 + 1 rows of CWB = 2 max_w + 2 bytes: the same nibbles one per BYTE, with an all-zero guard row
+//   (index R2) and guard column (index 2 max_w + 1) -- a lookup clamps its row / column with one v_min each instead of
+//   testing them (pw_expand4_v2_kernel keeps this table in LDS)
 struct PwPushDir {
   uint32_t pair_off;  // offset of pair table (0, 0) in 8-byte units from d_ovl; 0 = this puzzle has no push tables
   uint32_t wall_off;
   uint16_t R2, RW;
   uint16_t Hs, WW;
+  uint32_t pairb_off;   // byte pair tables, 8-byte units from d_ovl; 0 = none (too big for LDS)
+  uint16_t CWB;         // bytes per row of a byte pair table
+  uint16_t reserved;
+  uint32_t pairb_bytes; // N * N * (R2 + 1) * CWB rounded up to 16
+  uint32_t reserved2;
 };
 
 // An observation buffer owned by the library (pw_obs_alloc): one reserved address range backed by physical chunks
@@ -120,6 +128,8 @@ struct PwEngine {
   int step_boards;         // PW_OPT_STEP_BOARDS: 0 automatic (state-only launches of such sets), 2 never
   PwPushDir* d_push_dir;   // [set size], or NULL (sets of more than 64 puzzles carry no push tables)
   std::vector<uint8_t> push_has;  // [set size] host copy: puzzle p has push tables
+  std::vector<PwPushDir> push_host;  // [set size] host copy of d_push_dir
+  int expand_lds_tables;   // PW_OPT_EXPAND_LDS_TABLES: 0 automatic (pw_expand4_v2_kernel where the tables fit LDS), 2 never
   int64_t ovl_bytes;
   int ovl_puzzles;         // puzzles with tables
   std::vector<uint8_t> ovl_has;  // [set size] host copy: puzzle p has tables
@@ -137,6 +147,7 @@ struct PwEngine {
   // PW_OPT_PROFILE_RENDER: HIP event pairs around the dominant (render) launch, on the launch stream
   std::vector<hipEvent_t> prof_events;  // 2 per slot
   int prof_used;
+  int num_cus;             // compute units of the device (persistent launches)
   uint32_t* d_scratch;     // 64 bytes of device scratch (pw_validate_state counters) + one 4 KiB page of zeros
   unsigned long long* d_counters;  // PW_COUNTER_SLOTS x 8 uint64: env-steps / episodes ended / solved per slot (pw_counters)
   int64_t bad_total;       // out-of-range actions pw_engine_bad_actions has read and cleared so far (pw_counters adds the rest)

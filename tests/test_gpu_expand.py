@@ -65,6 +65,20 @@ def bfs(puzzle, max_states):
     "bench:level3/Armor.pwp|lanes", "bench:level3/Rocky Shore.pwp|lanes", "bench:level2/Bubbles.pwp|lanes",
     "bench:level3/Moving Mountains.pwp|lanes", "bench:level1/A Tight Squeeze.pwp|lanes",  # (N = 2: rows of one word)
     "bench:level2/Clean Sweep.pwp|lanes",  # 19 movables: the instance with 32 bits per action
+    # "lanes" runs pw_expand4_v2_kernel (push tables in LDS) wherever it applies -- 2 .. 16 movables, tables up to 48 KB --;
+    # "lanes-hbm": pw_expand4_lane_kernel (tables read through L1) for the same puzzles
+    "cpptest:trivial_tool2.pwp|lanes-hbm", "cpptest:blocked_transitive_pushing2.pwp|lanes-hbm",
+    "cpptest:necessary_transitive_pushing3.pwp|lanes-hbm", "cpptest:multiple_goals.pwp|lanes-hbm",
+    "bench:level1/2 Obstacle.pwp|lanes-hbm", "bench:level2/Pull Dont Push.pwp|lanes-hbm", "bench:level4/Four Pistons.pwp|lanes-hbm",
+    "bench:level3/Armor.pwp|lanes-hbm", "bench:level1/A Tight Squeeze.pwp|lanes-hbm",
+    # more movable counts for the LDS kernel's per-N instances (5, 8, 9, 10, 11, 14 ...)
+    # every movable count the LDS kernel is instantiated for: 4 .. 16 (2, 3, 6, 7, 12 are above)
+    "bench:level1/At Crossroads.pwp|lanes", "bench:level1/Building Blocks.pwp|lanes", "bench:level1/Pull Up.pwp|lanes",
+    "bench:level1/Dont Get Distracted.pwp|lanes", "bench:level1/Ignorable Obstacles.pwp|lanes",
+    "bench:level1/Irrelevant Obstacles.pwp|lanes", "bench:level2/Remote Obstacle.pwp|lanes", "bench:level3/Yin Yang.pwp|lanes",
+    "bench:level3/Chain Link Tunnel.pwp|lanes", "bench:level4/Tool Chain.pwp|lanes",
+    "bench:level2/Simultaneous Obstacle Removal.pwp|lanes", "bench:level3/Close But Far.pwp|lanes",
+    "bench:level3/Crow Pushing.pwp|lanes",
 ])
 def test_bfs_layers_match_oracle(golden, key):
     from oracle import c_oracle
@@ -77,8 +91,9 @@ def test_bfs_layers_match_oracle(golden, key):
     pz = PushWorldPuzzle(text=text, order="cpp")
     if tables == "wide":
         pz._engine().set_option("step_wide_groups", 1)
-    elif tables == "lanes":
+    elif tables in ("lanes", "lanes-hbm"):
         pz._engine().set_option("step_kernel", "lane")
+        pz._engine().set_option("expand_lds_tables", "never" if tables == "lanes-hbm" else "auto")
     elif tables:
         pz._engine().set_option("step_tables", tables)
         assert (pz._engine().get_option("step_table_puzzles") == 1) == (tables == "all")
@@ -125,7 +140,10 @@ def test_lane_kernel_with_unaligned_buffers_and_ragged_sizes(golden, key):
                 torch.empty((F, 4), dtype=torch.uint8, device=dev)]
         eng.expand4(0, st, *want)
         eng.set_option("step_kernel", "lane")
-        for off in (0, 1, 2):
+        for off in (0, 1, 2, 0):
+            # (aligned buffers: the kernel with the tables in LDS where the puzzle qualifies; the second aligned pass with that
+            # kernel switched off, i.e. pw_expand4_lane_kernel's 16-byte path)
+            eng.set_option("expand_lds_tables", "auto" if off else ("never" if eng.get_option("expand_lds_tables") == 0 and F == 65 else "auto"))
             raw = [torch.full((F * 4 * N + 8,), -7, dtype=torch.int32, device=dev), torch.full((F * 4 + 8,), -7, dtype=torch.int32, device=dev),
                    torch.full((F * 4 + 8,), 77, dtype=torch.uint8, device=dev)]
             got = [raw[0][off:off + F * 4 * N].view(F, 4, N), raw[1][off:off + F * 4].view(F, 4), raw[2][off:off + F * 4].view(F, 4)]

@@ -358,11 +358,14 @@ def c5_frontier(rel, target_states=4_000_000):
     exhausted = bfs.exhausted
     bfs.close()
     st = (xy[:, :, 0].astype(np.int64) * 10000 + xy[:, :, 1]).astype(np.int32)
-    return pz, st, exhausted
+    distinct = len(st)
+    if distinct < target_states:  # a state space smaller than the frontier asked for (`2 Obstacle`: 39 023 states): repeated
+        st = np.ascontiguousarray(np.tile(st, (-(-target_states // distinct), 1))[:target_states])
+    return pz, st, exhausted, distinct
 
 
 def run_c5(key, rel, cpu=True):
-    pz, st_host, exhausted = c5_frontier(rel)
+    pz, st_host, exhausted, distinct = c5_frontier(rel)
     F, N = st_host.shape
     dev = pz._engine().device
     per_parent = 20 * N + 20
@@ -383,10 +386,13 @@ def run_c5(key, rel, cpu=True):
     dt = wall(one, reps, nbuf)
     ms = launch_ms(eng, one, reps)
     out = entry(F / dt, "parents/s",
-                f"C5: pw_expand4 on the first {F} distinct states of a breadth-first search of {rel} (C++ object order, N = {N}; "
-                + ("the whole state space; " if exhausted else "") + f"{nbuf} disjoint buffer set(s), {nbuf * F * per_parent / 2**20:.0f} MB per cycle: beyond the 256 MB Infinity Cache)",
-                "pw_expand4_lane_kernel" if F >= eng.get_option("step_lane_batch") else "pw_expand4_kernel", per_parent, F, ms, key,
-                ms_per_launch=1e3 * dt, movables=int(N), states=int(F), buffer_sets=int(nbuf), successors_per_s=4 * F / dt)
+                f"C5: pw_expand4 on {F} states of a breadth-first search of {rel} in discovery order (C++ object order, N = {N}; {distinct} distinct"
+                + (" = the whole state space, repeated; " if distinct < F else "; ") + f"{nbuf} disjoint buffer set(s), {nbuf * F * per_parent / 2**20:.0f} MB per cycle: "
+                "beyond the 256 MB Infinity Cache)",
+                ("pw_expand4_v2_kernel" if eng.get_option("expand_lds_tables") == 0 and 2 <= N <= 16 else "pw_expand4_lane_kernel")
+                if F >= 131072 else "pw_expand4_kernel", per_parent, F, ms, key,
+                ms_per_launch=1e3 * dt, movables=int(N), states=int(F), distinct_states=int(distinct), buffer_sets=int(nbuf),
+                successors_per_s=4 * F / dt)
     del sets
     torch.cuda.empty_cache()
     if cpu:
@@ -433,8 +439,6 @@ def main():
     ap.add_argument("--only", default=None, help="comma-separated prefixes: C1,C2,C3_f32_ppc3,C4_state,C5 ...")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
     res = run_all(args.only.split(",") if args.only else None, not args.no_cpu, log=lambda s: print(s, file=sys.stderr, flush=True))
     print(json.dumps(res))
 

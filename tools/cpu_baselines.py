@@ -1,8 +1,9 @@
 """CPU baselines of bench.py (the ``cpu_baseline`` leg: the only place besides tests/ and smoke() that runs anything under
 ``oracle/``): the oracle's C port on this host's cores, on a bounded sample of the same workload.
 
-Stability: the OpenMP threads are pinned (``OMP_PROC_BIND=close OMP_PLACES=cores``, exported by bench.py
-before libgomp is loaded), every figure is the BEST of three samples, and all three values are reported."""
+Stability: every OpenMP thread pins itself to its own CPU (one hardware thread of every physical core
+first, then the SMT siblings: ``core_first_cpu_order``; OMP_PROC_BIND in the environment would also bind the thread that
+launches the GPU kernels), every figure is the BEST of three samples, and all three values are reported."""
 import ctypes
 import os
 import time
@@ -26,6 +27,66 @@ def hardware_threads():
         return len(os.sched_getaffinity(0))
     except AttributeError:
         return os.cpu_count() or 1
+
+
+def core_first_cpu_order():
+    """The CPUs this process may use, one hardware thread of every physical core first (in core order), then their SMT
+    siblings: thread t of a run pinned to entry t lands on its own core as long as there are cores left."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
+    seen, first, rest = set(), [], []
+    for cpu in allowed:
+        key = None
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+                key = f.read().strip()
+        except OSError:
+            key = str(cpu)
+        if key in seen:
+            rest.append(cpu)
+        else:
+            seen.add(key)
+            first.append(cpu)
+    return first + rest
+
+
+class pinned_threads:
+    """Context: the oracle's OpenMP threads pin themselves (``or_set_thread_cpus``); the calling thread's own mask is put back."""
+
+    def __enter__(self):
+        from oracle import c_oracle
+
+        self.c_oracle = c_oracle
+        try:
+            self.saved = os.sched_getaffinity(0)
+        except AttributeError:
+            self.saved = None
+        self.order = core_first_cpu_order()
+        c_oracle.set_thread_cpus(self.order)
+        return self
+
+    def __exit__(self, *exc):
+        self.c_oracle.set_thread_cpus([])
+        if self.saved is not None:
+            try:
+                os.sched_setaffinity(0, self.saved)
+            except OSError:
+                pass
+        return False
+
+
+def physical_cores():
+    order = core_first_cpu_order()
+    seen = set()
+    for cpu in order:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+                seen.add(f.read().strip())
+        except OSError:
+            seen.add(str(cpu))
+    return max(1, len(seen))
 
 
 def set_omp_threads(n):
@@ -54,11 +115,14 @@ def port_rollout_rate(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw,
     B = len(ids)
     rng = np.random.default_rng(12345)
 
+    render = {"u8": 1, "f32": 2}.get(render, render) if isinstance(render, str) else int(render)
+
     def timed(T, threads):
         acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
-        t0 = time.perf_counter()
-        _, used_threads = c_oracle.rollout(puzzles, ids, acts, max_steps, render, pad_h, pad_w, ppc, bw, threads=threads)
-        dt = time.perf_counter() - t0
+        with pinned_threads():
+            t0 = time.perf_counter()
+            _, used_threads = c_oracle.rollout(puzzles, ids, acts, max_steps, render, pad_h, pad_w, ppc, bw, threads=threads)
+            dt = time.perf_counter() - t0
         return B * T / dt, used_threads, dt
 
     def calibrated(threads):
@@ -73,7 +137,7 @@ def port_rollout_rate(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw,
     hw = hardware_threads()
     # all hardware threads this process may use, or one per physical core on an SMT-2 host: whichever is faster here
     best_threads, best_rate = 1, 0.0
-    for cand in sorted({hw, max(1, hw // 2)}):
+    for cand in sorted({hw, min(hw, physical_cores())}):
         rate = calibrated(cand)
         if rate > best_rate:
             best_threads, best_rate = cand, rate
@@ -89,12 +153,11 @@ def port_rollout_rate(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw,
 
     rate, vals, T2 = best_of(best_threads, best_rate, seconds)
     what = {0: "step only (no observation)", 1: f"step + padded uint8 render ppc={ppc}",
-            2: f"step + padded float32 render ppc={ppc}"}[{"u8": 1, "f32": 2}.get(render, int(render)) if isinstance(render, str) else int(render)]
+            2: f"step + padded float32 render ppc={ppc}"}[render]
     out = {
         "value": rate, "unit": "env-steps/s", "cores": best_threads, "kind": "port",
-        "sample": f"{B} envs (same puzzle mix) x {T2} steps, {what}, OpenMP over envs (OMP_PROC_BIND="
-                  f"{os.environ.get('OMP_PROC_BIND', 'unset')} OMP_PLACES={os.environ.get('OMP_PLACES', 'unset')}), "
-                  f"best of {samples} samples of ~{seconds:.1f} s",
+        "sample": f"{B} envs (same puzzle mix) x {T2} steps, {what}, OpenMP over envs, every thread pinned to its own CPU "
+                  f"(one per physical core first), best of {samples} samples of ~{seconds:.1f} s",
         "samples": vals,
     }
     if with_one_thread:
@@ -118,11 +181,12 @@ def port_expand_rate(text, states, seconds=1.0, samples=3):
     dt = time.perf_counter() - t0
     reps = int(max(1, min(64, seconds / max(dt, 1e-4))))
     vals = []
-    for _ in range(samples):
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            c_oracle.expand4_batch(pz, st)
-        vals.append(reps * len(st) / (time.perf_counter() - t0))
+    with pinned_threads():
+        for _ in range(samples):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                c_oracle.expand4_batch(pz, st)
+            vals.append(reps * len(st) / (time.perf_counter() - t0))
     return {"value": max(vals), "unit": "parents/s", "cores": threads, "kind": "port",
             "sample": f"{len(st)} states of the same frontier x {reps} passes, or_expand4_batch (OpenMP over states), best of {samples}",
             "samples": vals}
