@@ -494,6 +494,22 @@ int pw_search_read_flags(PwSearch* s, int64_t first, int64_t count, uint8_t* pru
  * is written: call again with a larger buffer) or a negative error. */
 int pw_search_plan(PwSearch* s, int64_t index, uint8_t* actions, int32_t cap, void* stream);
 
+/* Batched search of SMALL puzzles: ONE launch decides solvability for `n` puzzles of the engine's set (the filter of
+ * generate.py:262-297 over a generated set; best_first_search.h:45-98 with a FIFO frontier).  Persistent workgroups take
+ * puzzles off a device counter and run the whole breadth-first loop inside the kernel -- closed set in LDS (4 096 states)
+ * that moves to the workgroup's HBM slab when a layer could outgrow it, no launch per layer, no host readback.
+ *   puzzles     device int32 [n] set indices, NULL = 0 .. n - 1
+ *   verdict     device uint8 [n]: 1 solved, 0 unsolvable (reachable space exhausted), 2 unknown (more than
+ *               max_states_each states), 3 not searched -- the kernel handles grids up to 16 x 16 (with their border) and up
+ *               to 8 movables (every Level-0 recipe) of puzzles with overlap tables; search the others with pw_search_create
+ *   plan_len    device int32 [n]: length of a shortest plan (depth of the first goal state), -1 unless solved
+ *   num_states  optional device int32 [n]: states in the closed set when the search ended
+ * novelty_width must be 0 (breadth-first; the width-limited IW(k) is pw_search_create's).  The slabs (8 bytes per state of
+ * store + the tables, per persistent workgroup) are engine-owned, allocated on first use / growth (synchronises `stream`
+ * then) and kept.  Asynchronous on `stream` otherwise. */
+int pw_search_batch(PwEngine* e, const int32_t* puzzles, int32_t n, int64_t max_states_each, int32_t novelty_width,
+                    uint8_t* verdict, int32_t* plan_len, int32_t* num_states, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,14 +174,19 @@ def observe_batch(puzzles, puzzle_ids, pos, sel, pad_h, pad_w, ppc, bw, dtype="u
     return out
 
 
-def expand4_batch(puzzle, states):
-    """``states`` int32 [F, N] Position2D -> (succ int32 [F, 4, N], moved uint32 [F, 4], goal uint8 [F, 4])."""
+def expand4_batch(puzzle, states, out=None):
+    """``states`` int32 [F, N] Position2D -> (succ int32 [F, 4, N], moved uint32 [F, 4], goal uint8 [F, 4]); ``out``: the
+    three arrays of an earlier call, written in place (a timed loop must not pay for fresh pages every pass)."""
     states = np.ascontiguousarray(np.asarray(states, dtype=np.int32))
     F, N = states.shape
     assert N == puzzle.num_movables
-    succ = np.zeros((F, 4, N), np.int32)
-    moved = np.zeros((F, 4), np.uint32)
-    goal = np.zeros((F, 4), np.uint8)
+    if out is not None:
+        succ, moved, goal = out
+        assert succ.shape == (F, 4, N) and moved.shape == (F, 4) and goal.shape == (F, 4)
+    else:
+        succ = np.zeros((F, 4, N), np.int32)
+        moved = np.zeros((F, 4), np.uint32)
+        goal = np.zeros((F, 4), np.uint8)
     lib().or_expand4_batch(puzzle.handle, states.ctypes.data, F, succ.ctypes.data, moved.ctypes.data, goal.ctypes.data)
     return succ, moved, goal
 

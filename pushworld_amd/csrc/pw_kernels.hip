@@ -148,6 +148,8 @@ struct PwEngine {
   std::vector<hipEvent_t> prof_events;  // 2 per slot
   int prof_used;
   int num_cus;             // compute units of the device (persistent launches)
+  uint8_t* d_search_slab;  // pw_search_batch: work counter + one slab per persistent workgroup (grown on demand, kept)
+  size_t search_slab_bytes;
   uint32_t* d_scratch;     // 64 bytes of device scratch (pw_validate_state counters) + one 4 KiB page of zeros
   unsigned long long* d_counters;  // PW_COUNTER_SLOTS x 8 uint64: env-steps / episodes ended / solved per slot (pw_counters)
   int64_t bad_total;       // out-of-range actions pw_engine_bad_actions has read and cleared so far (pw_counters adds the rest)

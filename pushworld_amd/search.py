@@ -213,3 +213,27 @@ class NoveltyTables:
             self.handle = None
 
     __del__ = close
+
+
+VERDICT_UNSOLVABLE, VERDICT_SOLVED, VERDICT_UNKNOWN, VERDICT_NOT_SEARCHED = 0, 1, 2, 3
+
+
+def search_batch(engine, puzzle_indices=None, max_states: int = 1 << 16):
+    """``pw_search_batch``: breadth-first search of MANY small puzzles of ``engine``'s set in one launch (persistent workgroups,
+    the whole search loop inside the kernel).  Returns numpy arrays ``(verdict uint8 [n], plan_len int32 [n], num_states
+    int32 [n])``: verdict 1 solved (``plan_len`` = length of a shortest plan), 0 unsolvable, 2 unknown (more than
+    ``max_states`` states), 3 not searched (beyond 16 x 16 cells / 8 movables: use ``BreadthFirstSearch``)."""
+    dev = engine.device
+    if puzzle_indices is None:
+        n = len(engine.pset)
+        idx = None
+    else:
+        idx = torch.as_tensor(np.asarray(puzzle_indices), dtype=torch.int32).to(dev)
+        n = int(idx.shape[0])
+    verdict = torch.empty((n,), dtype=torch.uint8, device=dev)
+    plan_len = torch.empty((n,), dtype=torch.int32, device=dev)
+    states = torch.empty((n,), dtype=torch.int32, device=dev)
+    if n:
+        _capi.check(_capi.lib.pw_search_batch(engine.handle, _capi._ptr(idx), n, int(max_states), 0, _capi._ptr(verdict),
+                                              _capi._ptr(plan_len), _capi._ptr(states), engine._stream()))
+    return verdict.cpu().numpy(), plan_len.cpu().numpy(), states.cpu().numpy()

@@ -325,3 +325,110 @@ def test_width_limited_search_equals_host_model(golden, width, chunk, monkeypatc
         n_checked += 1
         bfs.close()
     assert n_checked >= 6 and n_pruned > 0 and n_solved >= 3
+
+
+# ---------------------------------------------------------------------------------------------- pw_search_batch
+def _host_bfs_verdict(oz, max_states):
+    """(verdict, plan_len, states) of a layer-synchronous breadth-first search with pw_search_batch's rules: a goal state
+    found in a layer decides (depth = plan length) even when the store fills up inside it; otherwise more than
+    ``max_states`` states = unknown."""
+    is_goal = oz.py.is_goal_state
+    s0 = oz.initial_state
+    if is_goal(s0):
+        return 1, 0, 1
+    seen = {s0}
+    layer, depth = [s0], 0
+    while layer:
+        nxt, found = [], False
+        for s in layer:
+            for a in range(4):
+                n = oz.get_next_state(s, a)
+                if n == s or n in seen:
+                    continue
+                seen.add(n)
+                nxt.append(n)
+                found = found or is_goal(n)
+        depth += 1
+        if found:
+            return 1, depth, len(seen)
+        if len(seen) > max_states:
+            return 2, -1, len(seen)
+        layer = nxt
+    return 0, -1, len(seen)
+
+
+def test_search_batch_equals_a_host_breadth_first_search(golden):
+    """One launch over a mixed set -- reference test puzzles, Level-0 puzzles, random puzzles, Level-1 puzzles of up to 8
+    movables on up to 16 x 16 cells, a puzzle beyond the kernel's limits -- against a host breadth-first search over the
+    oracle: verdict, shortest plan length and (for exhausted searches) the number of reachable states.  State caps of
+    300 / 5 000 / 200 000 put puzzles on every level of the closed set (LDS, 2^16 and 2^20 slots) and on the `unknown` path."""
+    from oracle import c_oracle
+    from pushworld_amd import _capi
+    from pushworld_amd.search import search_batch
+
+    keys = [k for k in golden.keys if k.startswith(("pytest:", "cpptest:", "rand:"))][:60] + \
+           [k for k in golden.keys if k.startswith("l0:")][::20] + \
+           [k for k in golden.keys if k.startswith("bench:level1/") and golden.meta[k]["num_movables"] <= 8
+            and golden.meta[k]["width"] <= 16 and golden.meta[k]["height"] <= 16][:12] + ["bench:level2/Clean Sweep.pwp"]
+    texts = [golden.text(k) for k in keys]
+    pset = _capi.PuzzleSet([_capi.ParsedPuzzle(t) for t in texts], 0)
+    eng = _capi.Engine(pset, None, 3, 1, _capi.OBS_U8)
+    oracles = [c_oracle.COraclePuzzle(t) for t in texts]
+    seen_verdicts = set()
+    for cap in (300, 5000, 200000):
+        verdict, plan_len, n_states = search_batch(eng, None, max_states=cap)
+        for i, k in enumerate(keys):
+            m = golden.meta[k]
+            if m["num_movables"] > 8 or m["width"] > 16 or m["height"] > 16:
+                assert verdict[i] == 3 and plan_len[i] == -1, k
+                continue
+            if cap == 200000 and not k.startswith(("pytest:", "cpptest:", "l0:")):
+                continue  # (the host search of a 200 000-state space in Python takes too long: the small caps cover these)
+            want_v, want_len, want_states = _host_bfs_verdict(oracles[i], cap)
+            assert (int(verdict[i]), int(plan_len[i])) == (want_v, want_len), (k, cap, int(n_states[i]), want_states)
+            if want_v == 0:
+                assert int(n_states[i]) == want_states, (k, cap)
+            seen_verdicts.add(want_v)
+    assert seen_verdicts == {0, 1, 2}
+    # a subset by index, in another order
+    sub = np.array([5, 0, 17, 3, 3], np.int32)
+    v_all, p_all, _ = search_batch(eng, None, max_states=5000)
+    v_sub, p_sub, _ = search_batch(eng, sub, max_states=5000)
+    assert (v_sub == v_all[sub]).all() and (p_sub == p_all[sub]).all()
+
+
+def test_batched_solvability_filter_equals_the_per_puzzle_search(torch_mod=None):
+    """The filter of generate.py:262-297 over 2 000 device-generated Level-0 puzzles: ONE pw_search_batch launch gives the
+    verdicts of the per-puzzle search (IW(2), then breadth-first search; a launch per pass and a readback per layer), and
+    the shortest plan lengths of the per-puzzle breadth-first search on a sample."""
+    import time
+
+    from pushworld_amd import _capi, generate
+    from pushworld_amd.search import BreadthFirstSearch, SetPuzzle, search_batch
+
+    pset, grids, dims = generate.generate_level0_set(2000, device=0, random_seed=21)
+    t0 = time.perf_counter()
+    keep = generate.solvable_mask(pset, max_states=300_000)
+    t_batched = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = generate.solvable_mask(pset, max_states=300_000, batched=False)
+    t_single = time.perf_counter() - t0
+    assert keep.tolist() == want.tolist() and 100 < keep.sum() < 2000
+    print(f"solvability filter, 2 000 puzzles: batched {t_batched:.3f} s, per puzzle {t_single:.1f} s")
+    eng = _capi.Engine(pset, None, 3, 1, _capi.OBS_U8)
+    verdict, plan_len, n_states = search_batch(eng, None, max_states=300_000)
+    assert ((verdict == 1) == keep).all() or (verdict == 2).any()
+    for i in np.nonzero(verdict == 1)[0][:40]:
+        bfs = BreadthFirstSearch(SetPuzzle(pset, int(i), eng), max_states=300_000)
+        bfs.begin()
+        while bfs.goal_index < 0 and not bfs.exhausted:
+            bfs.expand()
+        assert bfs.goal_index >= 0 and len(bfs.plan(bfs.goal_index)) == int(plan_len[i]), int(i)
+        bfs.close()
+    for i in np.nonzero(verdict == 0)[0][:20]:
+        bfs = BreadthFirstSearch(SetPuzzle(pset, int(i), eng), max_states=300_000)
+        bfs.begin()
+        while not bfs.exhausted:
+            bfs.expand()
+        assert bfs.goal_index < 0 and bfs.total_states == int(n_states[i]), int(i)
+        bfs.close()

@@ -175,17 +175,18 @@ def port_expand_rate(text, states, seconds=1.0, samples=3):
     pz = c_oracle.COraclePuzzle(text, order="cpp")
     threads = hardware_threads()
     set_omp_threads(threads)
-    st = np.ascontiguousarray(states[: min(len(states), 262144)])
-    t0 = time.perf_counter()
-    c_oracle.expand4_batch(pz, st)
-    dt = time.perf_counter() - t0
-    reps = int(max(1, min(64, seconds / max(dt, 1e-4))))
+    st = np.ascontiguousarray(states[: min(len(states), 1 << 20)])
     vals = []
     with pinned_threads():
+        out = c_oracle.expand4_batch(pz, st)  # (first pass: the output pages are touched here, not in the timed ones)
+        t0 = time.perf_counter()
+        c_oracle.expand4_batch(pz, st, out)
+        dt = time.perf_counter() - t0
+        reps = int(max(1, min(256, seconds / max(dt, 1e-4))))
         for _ in range(samples):
             t0 = time.perf_counter()
             for _ in range(reps):
-                c_oracle.expand4_batch(pz, st)
+                c_oracle.expand4_batch(pz, st, out)
             vals.append(reps * len(st) / (time.perf_counter() - t0))
     return {"value": max(vals), "unit": "parents/s", "cores": threads, "kind": "port",
             "sample": f"{len(st)} states of the same frontier x {reps} passes, or_expand4_batch (OpenMP over states), best of {samples}",
