@@ -183,6 +183,9 @@ OPTIONS = {
     "step_boards": 22,         # sets of 8 x 8 puzzles, state only: 0 / "auto" whole-grid boards in registers, 2 / "never"
     "step_board_set": 23,      # read-only: the set qualifies
     "expand_lds_tables": 24,   # pw_expand4, one lane per state: 0 / "auto" push tables in LDS where they fit, 2 / "never"
+    "expand_tile_order": 25,   # pw_expand4_v2_kernel: 0 tiles interleaved, 1 a contiguous eighth of the frontier per XCD
+    "expand_prefetch": 26,     # ... 1 = next tile's rows in flight while this one is computed
+    "expand_groups_per_cu": 27,  # ... persistent workgroups per CU (0 = automatic)
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2,

@@ -248,6 +248,30 @@ def test_full_small_images(golden, puzzles, torch_mod):
         assert (img == want).all(), (key, np.argwhere(img != want)[:5])
 
 
+def _assert_equals_oracle(vec, paths, ids, frame, ppc, bw, obs_kind, n=64):
+    """``n`` complete observations of ``vec``'s current states, spread over the batch, against the C ORACLE (painter of
+    puzzle.py:596-638 + padding of env_utils.py:65-91): pins whatever kernel / launch configuration ``vec`` renders with to the
+    reference, not to another HIP kernel."""
+    import torch
+
+    from oracle import c_oracle
+
+    if not hasattr(_assert_equals_oracle, "cache"):
+        _assert_equals_oracle.cache = {}
+    key = tuple(paths)
+    if key not in _assert_equals_oracle.cache:
+        _assert_equals_oracle.cache[key] = [c_oracle.COraclePuzzle(open(p).read()) for p in paths]
+    oracles = _assert_equals_oracle.cache[key]
+    B = vec.num_envs
+    sel = np.unique(np.linspace(0, B - 1, min(n, B)).astype(np.int64))
+    got = vec.obs[torch.as_tensor(sel).to(vec.device)].cpu().numpy()
+    want = c_oracle.observe_batch(oracles, ids, vec.states(), sel, frame[0], frame[1], ppc, bw, "f32" if obs_kind == "float32" else "u8")
+    assert got.dtype == want.dtype and got.shape == want.shape
+    diff = np.nonzero((got != want).any(axis=(1, 2, 3)))[0]
+    assert diff.size == 0, sel[diff[:5]]
+
+
+
 # (page order, log2 run, KiB of LDS padding[, every page loads])
 PAGE_CONFIGS = [None, (0, 0, 0), (1, 0, 0), (1, 0, 5), (1, 1, 3), (1, 2, 0), (1, 3, 1), (2, 0, 0), (2, 3, 7), (2, 6, 0),
                 (2, 11, 2), (2, 20, 9), (0, 0, 0, 1), (1, 1, 7, 1), (2, 6, 7, 1)]
@@ -288,12 +312,16 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
         o_alt = alt.step(acts[t])[0]
         assert torch.equal(ref.pos, alt.pos)
         assert torch.equal(o_ref, o_alt), t
+    # ... and THIS launch configuration against the oracle itself: 64 complete observations (every configuration the tuner may
+    # pick in production is pinned to the reference's painter, not only to another HIP kernel)
+    _assert_equals_oracle(alt, paths, ids, (51, 42), 3, 1, obs_kind)
     # overlapping states: every object at the position of its left neighbour in the state vector
     pos = ref.states()
     pos[:, 1:] = pos[:, :-1]
     for v in (ref, alt):
         v.set_states(pos)
     assert torch.equal(ref.render(), alt.render())
+    _assert_equals_oracle(alt, paths, ids, (51, 42), 3, 1, obs_kind)
     # the tuner leaves correct observations behind and a configuration from its candidate list
     idx = alt.engine.tune_render(alt.puzzle_id, alt.pos, alt._obs_storage)
     assert 0 <= idx < 20 and torch.equal(alt._obs_storage, ref._obs_storage)
@@ -351,11 +379,14 @@ def test_rowpage_render_matches_lds_kernel(golden, torch_mod, obs_kind, ppc, bw,
         o_alt = alt.step(acts[t])[0]
         assert torch.equal(ref.pos, alt.pos)
         assert torch.equal(o_ref, o_alt), t
+    frame = pad if pad is not None else (51, 42)
+    _assert_equals_oracle(alt, paths, ids, frame, ppc, bw, obs_kind, n=24 if ppc >= 16 else 64)  # this configuration vs the oracle
     pos = ref.states()
     pos[:, 1:] = pos[:, :-1]   # overlapping states: every object at the position of its left neighbour
     for v in (ref, alt):
         v.set_states(pos)
     assert torch.equal(ref.render(), alt.render())
+    _assert_equals_oracle(alt, paths, ids, frame, ppc, bw, obs_kind, n=24 if ppc >= 16 else 64)
     if B <= 64:  # the tuner on a small batch of big frames
         idx = alt.engine.tune_render(alt.puzzle_id, alt.pos, alt._obs_storage)
         assert 0 <= idx < 20 and torch.equal(alt._obs_storage, ref._obs_storage)
