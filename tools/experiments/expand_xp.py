@@ -12,7 +12,7 @@ from tools import config_suite as cs  # noqa: E402
 
 
 def main():
-    puzzles = sys.argv[1:] or ["level1/2 Obstacle.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp", "level3/Armor.pwp",
+    puzzles = [a for a in sys.argv[1:] if not a.startswith("--")] or ["level1/2 Obstacle.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp", "level3/Armor.pwp",
                                "level1/Pull Up.pwp"]
     for rel in puzzles:
         pz, st_host, exhausted, distinct = cs.c5_frontier(rel, 4_000_000)
@@ -25,10 +25,11 @@ def main():
                  torch.empty((F, 4), dtype=torch.int32, device=dev), torch.empty((F, 4), dtype=torch.uint8, device=dev)) for _ in range(nbuf)]
         ref = None
         variants = [("v1 (tables through L1)", {"expand_lds_tables": 2})]
-        for order in (0, 1):
-            for pre in (0, 1):
-                for gp in (0, 2, 4):
-                    variants.append((f"v2 order {order} prefetch {pre} groups/CU {gp or 'auto'}",
+        orders = (0, 1) if "--orders" in sys.argv else (0,)
+        for order in orders:
+            for pre in (-1, 0, 1):
+                for gp in ((0,) if pre < 0 else (1, 2, 3, 4, 5, 6, 8)):
+                    variants.append((f"v2 order {order} prefetch {'auto' if pre < 0 else pre} groups/CU {gp or 'auto'}",
                                      {"expand_lds_tables": 0, "expand_tile_order": order, "expand_prefetch": pre, "expand_groups_per_cu": gp}))
         for name, opts in variants:
             for k, v in opts.items():

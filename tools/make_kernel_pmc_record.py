@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the non-render kernels from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs with
+--kernel-trace only), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts the 128-byte requests of a wide coalesced
+read as 64 bytes on gfx950: doubled), one record per configuration of tools/config_suite.py:
+
+    python tools/make_kernel_pmc_record.py SOURCE  KEY:KERNEL_SUBSTRING:UNITS_PER_LAUNCH:FETCH_DB:WRITE_DB [...] > profiles/pmc_kernels_latest.json
+
+``UNITS_PER_LAUNCH`` selects the dispatches (grid sizes differ between the single-step launches and the rollouts of one
+profiled run: only dispatches whose duration-ordered position matches are not needed -- the caller passes one database pair per
+launch shape).  The record carries the sha of pushworld_amd/csrc: bench.py copies a record into its line only for the source
+it was measured on."""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def mean_counter(db, kernel, counter, grid=None):
+    con = sqlite3.connect(db)
+    q = ("select k.name, avg(p.counter_value), count(*), k.grid_x from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "
+         "where p.counter_name = ? group by k.name, k.grid_x")
+    rows = [r for r in con.execute(q, (counter,)).fetchall() if kernel in r[0] and (grid is None or int(r[3]) == int(grid))]
+    if not rows:
+        return None
+    total = sum(r[2] for r in rows)
+    return max(rows, key=lambda r: r[2])[0], sum(r[1] * r[2] for r in rows) / total, total, sorted({int(r[3]) for r in rows})
+
+
+def main():
+    from tools.config_suite import csrc_sha
+    from tools.make_pmc_record import git_head
+
+    source = sys.argv[1]
+    configs = {}
+    for spec in sys.argv[2:]:
+        parts = spec.split(":")
+        key, kernel, units, fetch_db, write_db = parts[:5]
+        grid = int(parts[5]) if len(parts) > 5 and parts[5] else None
+        f = mean_counter(fetch_db, kernel, "FETCH_SIZE", grid)
+        w = mean_counter(write_db, kernel, "WRITE_SIZE", grid)
+        if f is None or w is None:
+            print(f"no dispatches of {kernel!r} (grid {grid}) in {fetch_db} / {write_db}", file=sys.stderr)
+            continue
+        configs[key] = {"kernel_symbol": f[0], "units_per_launch": int(units), "hbm_bytes_per_launch": (2.0 * f[1] + w[1]) * 1024.0,
+                        "write_size_kb": w[1], "fetch_size_kb_raw": f[1], "dispatches": [f[2], w[2]], "grids": f[3]}
+    print(json.dumps({"configs": configs, "source": source, "csrc_sha16": csrc_sha(), "git_head": git_head(),
+                      "note": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, --kernel-trace only), mean over the "
+                              "dispatches of the kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B)"},
+                     indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--states", type=int, default=4_000_000)
     ap.add_argument("--puzzle", default="level4/Four Pistons.pwp")
     ap.add_argument("--lds-tables", default="auto", choices=("auto", "never"))
+    ap.add_argument("--rollouts", type=int, default=4, help="c4_step / c2_step: 64-step pw_rollout launches after the single steps")
     args = ap.parse_args()
     from tools import config_suite as cs
 
@@ -42,7 +43,7 @@ def main():
         torch.cuda.synchronize()
         for t in range(args.steps):
             vec.step(acts[t % 64])
-        for _ in range(4):
+        for _ in range(args.rollouts):
             vec.rollout(acts)
         torch.cuda.synchronize()
         print("c4_step done", args.steps, vec.counters())
@@ -57,7 +58,7 @@ def main():
         acts = cs.actions_for(64, 4096, vec.device, 0)
         for t in range(args.steps):
             vec.step(acts[t % 64])
-        for _ in range(4):
+        for _ in range(args.rollouts):
             vec.rollout(acts)
         torch.cuda.synchronize()
         print("c2_step done", vec.counters())
