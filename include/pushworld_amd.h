@@ -510,11 +510,14 @@ int pw_search_plan(PwSearch* s, int64_t index, uint8_t* actions, int32_t cap, vo
  *               to 8 movables (every Level-0 recipe) of puzzles with overlap tables; search the others with pw_search_create
  *   plan_len    device int32 [n]: length of a shortest plan (depth of the first goal state), -1 unless solved
  *   num_states  optional device int32 [n]: states in the closed set when the search ended
+ *   plans       optional device uint8 [n][plan_cap]: the actions of A shortest plan of every solved puzzle whose plan fits
+ *               plan_cap (the layers are not numbered in FIFO order here: pw_search_plan's plan is the first in action order,
+ *               this one is any of the same length); costs 4 more bytes per state of slab
  * novelty_width must be 0 (breadth-first; the width-limited IW(k) is pw_search_create's).  The slabs (8 bytes per state of
  * store + the tables, per persistent workgroup) are engine-owned, allocated on first use / growth (synchronises `stream`
  * then) and kept.  Asynchronous on `stream` otherwise. */
 int pw_search_batch(PwEngine* e, const int32_t* puzzles, int32_t n, int64_t max_states_each, int32_t novelty_width,
-                    uint8_t* verdict, int32_t* plan_len, int32_t* num_states, void* stream);
+                    uint8_t* verdict, int32_t* plan_len, int32_t* num_states, uint8_t* plans, int32_t plan_cap, void* stream);
 
 #ifdef __cplusplus
 }

@@ -151,7 +151,8 @@ SIGNATURES = {
     "pw_obs_alloc_tuned": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, POINTER(c_void_p),
                                    POINTER(ctypes.c_float), POINTER(c_int32), c_void_p]),
     "pw_obs_free": (c_int, [c_void_p, c_void_p]),
-    "pw_search_batch": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pw_search_batch": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                c_void_p]),
     "pw_counters": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
     "pw_counters_reset": (c_int, [c_void_p, c_void_p]),
     "pw_next_state": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),

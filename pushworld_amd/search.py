@@ -218,11 +218,12 @@ class NoveltyTables:
 VERDICT_UNSOLVABLE, VERDICT_SOLVED, VERDICT_UNKNOWN, VERDICT_NOT_SEARCHED = 0, 1, 2, 3
 
 
-def search_batch(engine, puzzle_indices=None, max_states: int = 1 << 16):
+def search_batch(engine, puzzle_indices=None, max_states: int = 1 << 16, plan_cap: int = 0):
     """``pw_search_batch``: breadth-first search of MANY small puzzles of ``engine``'s set in one launch (persistent workgroups,
     the whole search loop inside the kernel).  Returns numpy arrays ``(verdict uint8 [n], plan_len int32 [n], num_states
     int32 [n])``: verdict 1 solved (``plan_len`` = length of a shortest plan), 0 unsolvable, 2 unknown (more than
-    ``max_states`` states), 3 not searched (beyond 16 x 16 cells / 8 movables: use ``BreadthFirstSearch``)."""
+    ``max_states`` states), 3 not searched (beyond 16 x 16 cells / 8 movables: use ``BreadthFirstSearch``).  With
+    ``plan_cap`` > 0 a fourth value: the list of plans (lists of actions; None where there is none or it is longer)."""
     dev = engine.device
     if puzzle_indices is None:
         n = len(engine.pset)
@@ -233,7 +234,23 @@ def search_batch(engine, puzzle_indices=None, max_states: int = 1 << 16):
     verdict = torch.empty((n,), dtype=torch.uint8, device=dev)
     plan_len = torch.empty((n,), dtype=torch.int32, device=dev)
     states = torch.empty((n,), dtype=torch.int32, device=dev)
+    plans = torch.zeros((n, plan_cap), dtype=torch.uint8, device=dev) if plan_cap > 0 else None
     if n:
         _capi.check(_capi.lib.pw_search_batch(engine.handle, _capi._ptr(idx), n, int(max_states), 0, _capi._ptr(verdict),
-                                              _capi._ptr(plan_len), _capi._ptr(states), engine._stream()))
-    return verdict.cpu().numpy(), plan_len.cpu().numpy(), states.cpu().numpy()
+                                              _capi._ptr(plan_len), _capi._ptr(states), _capi._ptr(plans), int(plan_cap),
+                                              engine._stream()))
+    v, pl, ns = verdict.cpu().numpy(), plan_len.cpu().numpy(), states.cpu().numpy()
+    if plan_cap <= 0:
+        return v, pl, ns
+    ph = plans.cpu().numpy()
+    return v, pl, ns, [ph[i, :pl[i]].tolist() if v[i] == VERDICT_SOLVED and 0 <= pl[i] <= plan_cap else None for i in range(n)]
+
+
+def shortest_plan(puzzle, max_states: int = 1 << 20, plan_cap: int = 4096):
+    """``(plan, verdict)`` of ONE puzzle from a single launch (``pw_search_batch`` with n = 1): the whole breadth-first search
+    runs inside the kernel, so a search of a few dozen states costs one launch and one readback instead of a handful of
+    launches and a readback per layer.  ``plan`` is a shortest plan (list of actions) or None; verdict as ``search_batch``.
+    Puzzles beyond the kernel's limits (verdict 3) and searches beyond ``max_states`` (2) are ``BreadthFirstSearch``'s."""
+    eng = puzzle._engine()
+    v, pl, ns, plans = search_batch(eng, [int(getattr(puzzle, "puzzle_index", 0))], max_states=max_states, plan_cap=plan_cap)
+    return plans[0], int(v[0])

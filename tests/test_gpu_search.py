@@ -390,6 +390,26 @@ def test_search_batch_equals_a_host_breadth_first_search(golden):
                 assert int(n_states[i]) == want_states, (k, cap)
             seen_verdicts.add(want_v)
     assert seen_verdicts == {0, 1, 2}
+    # plans: A shortest plan of every solved puzzle, valid under the oracle (replayed from the initial state)
+    v_p, l_p, _, plans = search_batch(eng, None, max_states=5000, plan_cap=64)
+    v_all, p_all, _ = search_batch(eng, None, max_states=5000)
+    assert (v_p == v_all).all() and (l_p == p_all).all()
+    n_plans = 0
+    for i, k in enumerate(keys):
+        if v_p[i] != 1:
+            assert plans[i] is None
+            continue
+        if l_p[i] > 64:
+            assert plans[i] is None
+            continue
+        assert len(plans[i]) == l_p[i]
+        s = oracles[i].initial_state
+        for a in plans[i]:
+            assert not oracles[i].py.is_goal_state(s), k  # (a shortest plan reaches the goal with its last action only)
+            s = oracles[i].get_next_state(s, a)
+        assert oracles[i].py.is_goal_state(s), k
+        n_plans += 1
+    assert n_plans >= 20
     # a subset by index, in another order
     sub = np.array([5, 0, 17, 3, 3], np.int32)
     v_all, p_all, _ = search_batch(eng, None, max_states=5000)
@@ -441,3 +461,37 @@ def test_batched_solvability_filter_equals_the_per_puzzle_search(torch_mod=None)
             bfs.expand()
         assert bfs.goal_index < 0 and bfs.total_states == int(n_states[i]), int(i)
         bfs.close()
+
+
+def test_shortest_plan_is_one_launch_for_small_searches(golden):
+    """``shortest_plan`` (pw_search_batch with n = 1) against the layer-synchronous BreadthFirstSearch on the small Level-1
+    puzzles: same plan length (both breadth-first), a valid plan, and for `Choose Wisely` (59 states, 21 layers -- 0.9 ms
+    through the per-layer launches) the whole search in a fraction of that."""
+    import time
+
+    import torch
+
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.search import BreadthFirstSearch, shortest_plan
+
+    for key in ("bench:level1/Choose Wisely.pwp", "bench:level1/2 Obstacle.pwp", "pytest:trivial_obstacle.pwp"):
+        if key not in golden.meta:
+            continue
+        pz = PushWorldPuzzle(text=golden.text(key))
+        plan, verdict = shortest_plan(pz)
+        assert verdict == 1 and pz.is_valid_plan(plan), key
+        bfs = BreadthFirstSearch(pz, max_states=1 << 20)
+        bfs.begin()
+        while bfs.goal_index < 0 and not bfs.exhausted:
+            bfs.expand()
+        assert len(bfs.plan(bfs.goal_index)) == len(plan), key
+        bfs.close()
+    pz = PushWorldPuzzle(text=golden.text("bench:level1/Choose Wisely.pwp"))
+    shortest_plan(pz)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        shortest_plan(pz)
+    dt = (time.perf_counter() - t0) / 20
+    print(f"Choose Wisely: shortest_plan {dt * 1e6:.0f} us per search")
+    assert dt < 0.5e-3

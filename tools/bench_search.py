@@ -81,6 +81,19 @@ def main():
             ent["plan_length"] = len(plan)
             ent["plan_valid"] = bool(pz.is_valid_plan(plan))
         ent["host_fifo_parents_per_s"] = host_rate(text)
+        if bfs.total_states <= (1 << 18) and status != "store full":
+            # the same search as ONE launch (pw_search_batch with n = 1: the whole loop inside the kernel)
+            from pushworld_amd.search import shortest_plan
+
+            shortest_plan(pz)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                plan1, v1 = shortest_plan(pz)
+            dt1 = (time.perf_counter() - t1) / reps
+            ent["single_launch"] = {"seconds": dt1, "parents_per_s": expanded / dt1, "verdict": int(v1),
+                                    "plan_length": None if plan1 is None else len(plan1)}
         out[rel] = ent
         bfs.close()
     print(json.dumps(out, indent=1))
