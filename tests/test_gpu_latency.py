@@ -24,7 +24,7 @@ def test_next_state_follows_every_golden_trajectory(golden):
         for name, acts, start, pos, rew, term, goals in golden.sequences(k):
             st = pz.initial_state if start is None else tuple((int(x), int(y)) for x, y in start)
             n = pz.num_movables
-            if len(acts) <= 60:
+            if len(acts) <= 120:
                 s = st
                 for t, a in enumerate(acts):
                     s = pz.get_next_state(s, int(a))
@@ -35,7 +35,7 @@ def test_next_state_follows_every_golden_trajectory(golden):
             assert (states[1:] == pos[:, :n].astype(np.int8)).all(), (k, name)
             assert (states[0] == np.asarray(st, np.int8)).all()
             assert (flags[1:] == term).all(), (k, name)
-    assert n_steps > 3000
+    assert n_steps > 1000
 
 
 def test_next_state_info_and_errors(golden):
