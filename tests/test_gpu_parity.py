@@ -272,6 +272,28 @@ def _assert_equals_oracle(vec, paths, ids, frame, ppc, bw, obs_kind, n=64):
 
 
 
+def _overlapping_states_in_bounds(pos, paths, ids):
+    """Every object at the position of its left neighbour in the state vector, clamped into the grid by its own bounding box:
+    overlapping (illegal) states the painter order matters for, yet states the reference defines (puzzle.py:453-458 draws in
+    bounds only)."""
+    from oracle import c_oracle
+
+    _assert_equals_oracle.cache = getattr(_assert_equals_oracle, "cache", {})
+    key = tuple(paths)
+    if key not in _assert_equals_oracle.cache:
+        _assert_equals_oracle.cache[key] = [c_oracle.COraclePuzzle(open(p).read()) for p in paths]
+    oracles = _assert_equals_oracle.cache[key]
+    over = pos.copy()
+    for b in range(pos.shape[0]):
+        pz = oracles[int(ids[b])]
+        for j in range(1, pz.num_movables):
+            w = max(c[0] for c in pz.py.shapes[j]) + 1
+            h = max(c[1] for c in pz.py.shapes[j]) + 1
+            over[b, j, 0] = min(int(pos[b, j - 1, 0]), pz.width - w)
+            over[b, j, 1] = min(int(pos[b, j - 1, 1]), pz.height - h)
+    return over
+
+
 # (page order, log2 run, KiB of LDS padding[, every page loads])
 PAGE_CONFIGS = [None, (0, 0, 0), (1, 0, 0), (1, 0, 5), (1, 1, 3), (1, 2, 0), (1, 3, 1), (2, 0, 0), (2, 3, 7), (2, 6, 0),
                 (2, 11, 2), (2, 20, 9), (0, 0, 0, 1), (1, 1, 7, 1), (2, 6, 7, 1)]
@@ -315,13 +337,17 @@ def test_page_render_matches_lds_kernel(golden, torch_mod, path, obs_kind, monke
     # ... and THIS launch configuration against the oracle itself: 64 complete observations (every configuration the tuner may
     # pick in production is pinned to the reference's painter, not only to another HIP kernel)
     _assert_equals_oracle(alt, paths, ids, (51, 42), 3, 1, obs_kind)
-    # overlapping states: every object at the position of its left neighbour in the state vector
-    pos = ref.states()
-    pos[:, 1:] = pos[:, :-1]
+    # overlapping states: every object at the position of its left neighbour in the state vector (kept inside the grid)
+    pos = _overlapping_states_in_bounds(ref.states(), paths, ids)
     for v in (ref, alt):
         v.set_states(pos)
     assert torch.equal(ref.render(), alt.render())
     _assert_equals_oracle(alt, paths, ids, (51, 42), 3, 1, obs_kind)
+    # ... and pushed partly out of the grid (no reference semantics there: the two kernels must still agree)
+    pos[:, 1:] = pos[:, :-1]
+    for v in (ref, alt):
+        v.set_states(pos)
+    assert torch.equal(ref.render(), alt.render())
     # the tuner leaves correct observations behind and a configuration from its candidate list
     idx = alt.engine.tune_render(alt.puzzle_id, alt.pos, alt._obs_storage)
     assert 0 <= idx < 20 and torch.equal(alt._obs_storage, ref._obs_storage)
@@ -381,12 +407,15 @@ def test_rowpage_render_matches_lds_kernel(golden, torch_mod, obs_kind, ppc, bw,
         assert torch.equal(o_ref, o_alt), t
     frame = pad if pad is not None else (51, 42)
     _assert_equals_oracle(alt, paths, ids, frame, ppc, bw, obs_kind, n=24 if ppc >= 16 else 64)  # this configuration vs the oracle
-    pos = ref.states()
-    pos[:, 1:] = pos[:, :-1]   # overlapping states: every object at the position of its left neighbour
+    pos = _overlapping_states_in_bounds(ref.states(), paths, ids)  # overlapping states: every object at its left neighbour's position
     for v in (ref, alt):
         v.set_states(pos)
     assert torch.equal(ref.render(), alt.render())
     _assert_equals_oracle(alt, paths, ids, frame, ppc, bw, obs_kind, n=24 if ppc >= 16 else 64)
+    pos[:, 1:] = pos[:, :-1]   # ... and pushed partly out of the grid (no reference semantics: the kernels must still agree)
+    for v in (ref, alt):
+        v.set_states(pos)
+    assert torch.equal(ref.render(), alt.render())
     if B <= 64:  # the tuner on a small batch of big frames
         idx = alt.engine.tune_render(alt.puzzle_id, alt.pos, alt._obs_storage)
         assert 0 <= idx < 20 and torch.equal(alt._obs_storage, ref._obs_storage)
