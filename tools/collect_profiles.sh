@@ -39,9 +39,11 @@ prof3 search --what search --puzzle "level2/Pull Dont Push.pwp" --states 4000000
 prof3 batch --what batch --states 20000 --steps 8
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d $P -o x4p_sq1 -- python tools/profile_kernels.py --what expand --puzzle "level4/Four Pistons.pwp" --steps 6 > $P/x4p_sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d $P -o x4p_sq2 -- python tools/profile_kernels.py --what expand --puzzle "level4/Four Pistons.pwp" --steps 6 > $P/x4p_sq2.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d $P -o x2ob_sq1 -- python tools/profile_kernels.py --what expand --puzzle "level1/2 Obstacle.pwp" --steps 6 > $P/x2ob_sq1.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d $P -o xpdp_sq1 -- python tools/profile_kernels.py --what expand --puzzle "level2/Pull Dont Push.pwp" --steps 6 > $P/xpdp_sq1.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d $P -o c4_sq1 -- python tools/profile_kernels.py --what c4_step --steps 40 --rollouts 4 > $P/c4_sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace -d $P -o c4_sq2 -- python tools/profile_kernels.py --what c4_step --steps 40 --rollouts 4 > $P/c4_sq2.log 2>&1
-for f in x4p_sq1 x4p_sq2 c4_sq1 c4_sq2; do python tools/rocprof_summary.py $P/${f}_results.db 2>&1 | grep -v "at::\|rocclr\|hipMem\|Cijk\|__amd" > $P/${f}_summary.txt; done
+for f in x4p_sq1 x4p_sq2 c4_sq1 c4_sq2 x2ob_sq1 xpdp_sq1; do python tools/rocprof_summary.py $P/${f}_results.db 2>&1 | grep -v "at::\|rocclr\|hipMem\|Cijk\|__amd" > $P/${f}_summary.txt; done
 python tools/make_kernel_pmc_record.py "tools/collect_profiles.sh $TAG" \
   "C4_state:pw_step_group_mixed_kernel<true>:65536:$P/c4_fetch_results.db:$P/c4_write_results.db" \
   "C4_rollout:pw_step_group_mixed_kernel<false>:4194304:$P/c4_fetch_results.db:$P/c4_write_results.db" \
