@@ -167,29 +167,35 @@ def port_rollout_rate(texts, ids_full, max_steps, render, pad_h, pad_w, ppc, bw,
     return out
 
 
-def port_expand_rate(text, states, seconds=1.0, samples=3):
+def port_expand_rate(text, states, seconds=0.5, samples=3):
     """parents/s of the C port's 4-action expansion (``or_expand4_batch``, OpenMP over states) on a sample of the same
-    frontier, C++ object order."""
+    frontier, C++ object order: one thread per physical core or all hardware threads, whichever is faster on this host
+    (all 256 hardware threads of the bench boxes are 10x SLOWER than 128 here), every thread pinned, best of three samples."""
     from oracle import c_oracle
 
     pz = c_oracle.COraclePuzzle(text, order="cpp")
-    threads = hardware_threads()
-    set_omp_threads(threads)
     st = np.ascontiguousarray(states[: min(len(states), 1 << 20)])
-    vals = []
+    best = None
     with pinned_threads():
         out = c_oracle.expand4_batch(pz, st)  # (first pass: the output pages are touched here, not in the timed ones)
-        t0 = time.perf_counter()
-        c_oracle.expand4_batch(pz, st, out)
-        dt = time.perf_counter() - t0
-        reps = int(max(1, min(256, seconds / max(dt, 1e-4))))
-        for _ in range(samples):
+        for threads in sorted({min(hardware_threads(), physical_cores()), hardware_threads()}):
+            set_omp_threads(threads)
+            c_oracle.expand4_batch(pz, st, out)
             t0 = time.perf_counter()
-            for _ in range(reps):
-                c_oracle.expand4_batch(pz, st, out)
-            vals.append(reps * len(st) / (time.perf_counter() - t0))
-    return {"value": max(vals), "unit": "parents/s", "cores": threads, "kind": "port",
-            "sample": f"{len(st)} states of the same frontier x {reps} passes, or_expand4_batch (OpenMP over states), best of {samples}",
+            c_oracle.expand4_batch(pz, st, out)
+            dt = time.perf_counter() - t0
+            reps = int(max(2, min(512, seconds / max(dt, 1e-4))))
+            vals = []
+            for _ in range(samples):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    c_oracle.expand4_batch(pz, st, out)
+                vals.append(reps * len(st) / (time.perf_counter() - t0))
+            if best is None or max(vals) > best[0]:
+                best = (max(vals), vals, threads, reps)
+    rate, vals, threads, reps = best
+    return {"value": rate, "unit": "parents/s", "cores": threads, "kind": "port",
+            "sample": f"{len(st)} states of the same frontier x {reps} passes, or_expand4_batch (OpenMP over states, pinned threads), best of {samples}",
             "samples": vals}
 
 
