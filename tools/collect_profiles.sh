@@ -44,7 +44,22 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d $P -o c4_sq1 -- python tools/profile_kernels.py --what c4_step --steps 40 --rollouts 4 > $P/c4_sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace -d $P -o c4_sq2 -- python tools/profile_kernels.py --what c4_step --steps 40 --rollouts 4 > $P/c4_sq2.log 2>&1
 for f in x4p_sq1 x4p_sq2 c4_sq1 c4_sq2 x2ob_sq1 xpdp_sq1; do python tools/rocprof_summary.py $P/${f}_results.db 2>&1 | grep -v "at::\|rocclr\|hipMem\|Cijk\|__amd" > $P/${f}_summary.txt; done
+# the other render settings of the configuration suite (tools/profile_hotpath.py builds them as bench.py does)
+hot3() {  # name, then the profile_hotpath.py arguments
+  local name=$1; shift
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P -o ${name}_fetch -- python tools/profile_hotpath.py "$@" > $P/${name}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P -o ${name}_write -- python tools/profile_hotpath.py "$@" > $P/${name}_write.log 2>&1
+  for f in fetch write; do
+    python tools/rocprof_summary.py $P/${name}_${f}_results.db 2>&1 | grep -v "at::\|rocclr\|hipMem\|Cijk\|__amd" > $P/${name}_${f}_summary.txt
+  done
+}
+hot3 c3f3 --steps 6 --obs float32
+hot3 c3f20 --steps 4 --obs float32 --ppc 20 --bw 2 --envs 8192
+hot3 c4u8 --steps 6 --config c4
 python tools/make_kernel_pmc_record.py "tools/collect_profiles.sh $TAG" \
+  "C3_f32_ppc3:pw_render_page_kernel<float:65536:$P/c3f3_fetch_results.db:$P/c3f3_write_results.db" \
+  "C3_f32_ppc20_8192:pw_render_rowpage_kernel<float:8192:$P/c3f20_fetch_results.db:$P/c3f20_write_results.db::3" \
+  "C4_u8_ppc3:pw_render_page_kernel<unsigned char:65536:$P/c4u8_fetch_results.db:$P/c4u8_write_results.db" \
   "C4_state:pw_step_group_mixed_kernel<true>:65536:$P/c4_fetch_results.db:$P/c4_write_results.db" \
   "C4_rollout:pw_step_group_mixed_kernel<false>:4194304:$P/c4_fetch_results.db:$P/c4_write_results.db" \
   "C2_step:pw_step_board_kernel:4096:$P/c2s_fetch_results.db:$P/c2s_write_results.db" \

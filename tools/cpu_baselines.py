@@ -176,9 +176,10 @@ def port_expand_rate(text, states, seconds=0.5, samples=3):
     pz = c_oracle.COraclePuzzle(text, order="cpp")
     st = np.ascontiguousarray(states[: min(len(states), 1 << 20)])
     best = None
+    candidates = sorted({min(hardware_threads(), physical_cores()), hardware_threads()})  # (before the calling thread is pinned)
     with pinned_threads():
         out = c_oracle.expand4_batch(pz, st)  # (first pass: the output pages are touched here, not in the timed ones)
-        for threads in sorted({min(hardware_threads(), physical_cores()), hardware_threads()}):
+        for threads in candidates:
             set_omp_threads(threads)
             c_oracle.expand4_batch(pz, st, out)
             t0 = time.perf_counter()
