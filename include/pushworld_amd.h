@@ -271,8 +271,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       buffers) wherever it applies, 2 never (tables read from HBM through L1) */
 #define PW_OPT_EXPAND_TILE_ORDER 25    /* pw_expand4_v2_kernel: which 64-state tiles a wavefront takes: 0 interleaved over the workgroups,
                                       1 XCD x (workgroup index mod 8) sweeps the x-th contiguous eighth of the frontier */
-#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: 1 = the next tile's parent rows are loaded while this tile is computed, 0 not,
-                                      -1 (default) automatic: for puzzles of up to 7 movables */
+#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: 2 (= -1, the default) the parent rows of the tile after next are requested, and the
+                                      next tile's taken over, just before a tile's stores are issued; 0 a tile loads its rows at its top */
 #define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU (0 = automatic: 4 up to 7 movables, 2 beyond,
                                       within what its LDS allows) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
