@@ -25,10 +25,10 @@ def main():
                  torch.empty((F, 4), dtype=torch.int32, device=dev), torch.empty((F, 4), dtype=torch.uint8, device=dev)) for _ in range(nbuf)]
         ref = None
         variants = [("v1 (tables through L1)", {"expand_lds_tables": 2})]
-        orders = (0, 1) if "--orders" in sys.argv else (0,)
+        orders = (0, 1, 2) if "--orders" in sys.argv else (0, 2)  # (2: plain stores instead of non-temporal ones)
         for order in orders:
             for pre in (-1, 0, 2):  # 0: stores at the end of a tile (kPipe 0), 2: one tile late (kPipe 1)
-                for gp in ((0,) if pre < 0 else (2, 3, 4, 5, 6, 8)):
+                for gp in ((0,) if pre < 0 else (2, 3, 4, 8)):
                     variants.append((f"v2 order {order} prefetch {'auto' if pre < 0 else pre} groups/CU {gp or 'auto'}",
                                      {"expand_lds_tables": 0, "expand_tile_order": order, "expand_prefetch": pre, "expand_groups_per_cu": gp}))
         for name, opts in variants:
