@@ -270,11 +270,14 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       LDS (pw_expand4_v2_kernel: 2 .. 16 movables, tables up to 48 KB, 16-byte aligned output
                                       buffers) wherever it applies, 2 never (tables read from HBM through L1) */
 #define PW_OPT_EXPAND_TILE_ORDER 25    /* pw_expand4_v2_kernel: which 64-state tiles a wavefront takes: 0 interleaved over the workgroups,
-                                      1 XCD x (workgroup index mod 8) sweeps the x-th contiguous eighth of the frontier */
-#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: 2 (= -1, the default) the parent rows of the tile after next are requested, and the
-                                      next tile's taken over, just before a tile's stores are issued; 0 a tile loads its rows at its top */
-#define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU (0 = automatic: 4 up to 7 movables, 2 beyond,
-                                      within what its LDS allows) */
+                                      1 XCD x (workgroup index mod 8) sweeps the x-th contiguous eighth of the frontier; + 2: plain
+                                      instead of non-temporal stores (A/B measurements only) */
+#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: -1 / 2 (the default) software pipeline -- a tile's successors stay staged in
+                                      LDS and leave, as non-temporal whole-line stores, after the NEXT tile's parent rows have been
+                                      requested; 0 a tile loads its rows at its top and stores at its end (also what runs where the
+                                      pipeline's staging does not fit in 80 KB of LDS) */
+#define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU (0 = automatic: 8; those that do not fit at
+                                      once queue up behind the others) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

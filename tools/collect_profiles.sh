@@ -64,9 +64,9 @@ python tools/make_kernel_pmc_record.py "tools/collect_profiles.sh $TAG" \
   "C4_rollout:pw_step_group_mixed_kernel<false>:4194304:$P/c4_fetch_results.db:$P/c4_write_results.db" \
   "C2_step:pw_step_board_kernel:4096:$P/c2s_fetch_results.db:$P/c2s_write_results.db" \
   "C2_rollout:pw_step_board_kernel:262144:$P/c2r_fetch_results.db:$P/c2r_write_results.db" \
-  "C5_2_obstacle:pw_expand4_v2_kernel<3>:4000000:$P/x2ob_fetch_results.db:$P/x2ob_write_results.db" \
-  "C5_pull_dont_push:pw_expand4_v2_kernel<6>:4000000:$P/xpdp_fetch_results.db:$P/xpdp_write_results.db" \
-  "C5_four_pistons:pw_expand4_v2_kernel<12>:4000000:$P/x4p_fetch_results.db:$P/x4p_write_results.db" \
+  "C5_2_obstacle:pw_expand4_v2_kernel<3,:4000000:$P/x2ob_fetch_results.db:$P/x2ob_write_results.db" \
+  "C5_pull_dont_push:pw_expand4_v2_kernel<6,:4000000:$P/xpdp_fetch_results.db:$P/xpdp_write_results.db" \
+  "C5_four_pistons:pw_expand4_v2_kernel<12,:4000000:$P/x4p_fetch_results.db:$P/x4p_write_results.db" \
   > $P/pmc_kernels_latest.json 2> $P/pmc_kernels.err
 rm -f $P/*.db
 tail -1 $P/bench.json | cut -c1-400
