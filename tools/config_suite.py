@@ -382,7 +382,7 @@ def run_c5(key, rel, cpu=True):
         it[0] += 1
         eng.expand4(0, s[0], s[1], s[2], s[3])
 
-    reps = max(8, 2 * nbuf)
+    reps = max(40, 4 * nbuf)
     dt = wall(one, reps, nbuf)
     ms = launch_ms(eng, one, reps)
     out = entry(F / dt, "parents/s",
