@@ -278,6 +278,7 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       pipeline's staging does not fit in 80 KB of LDS) */
 #define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU (0 = automatic: 8; those that do not fit at
                                       once queue up behind the others) */
+#define PW_OPT_SEARCH_BATCH_GROUPS_PER_CU 28 /* pw_search_batch: persistent workgroups per CU (0 = automatic) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

@@ -7,9 +7,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from pushworld_amd import _capi, generate
 from pushworld_amd.search import search_batch
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4000
 pset, grids, dims = generate.generate_level0_set(n, device=0, random_seed=21)
 eng = _capi.Engine(pset, None, 3, 1, _capi.OBS_U8)
+if "--groups" in sys.argv:  # A/B of PW_OPT_SEARCH_BATCH_GROUPS_PER_CU
+    for cap in (1 << 14, 1 << 16, 1 << 18):
+        for g in (1, 2, 3, 4, 6, 8):
+            eng.set_option("search_batch_groups_per_cu", g)
+            search_batch(eng, None, max_states=cap)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                v, pl, ns = search_batch(eng, None, max_states=cap)
+                best = min(best, time.perf_counter() - t0)
+            print(f"cap {cap:8d} groups/CU {g}: {n / best:9.0f} puzzles/s ({best * 1e3:7.2f} ms)  {ns.sum() / best:10.3e} states/s", flush=True)
+    eng.set_option("search_batch_groups_per_cu", 0)
+    sys.exit(0)
 for cap in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 21):
     search_batch(eng, None, max_states=cap)
     torch.cuda.synchronize()
