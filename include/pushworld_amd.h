@@ -272,12 +272,12 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_EXPAND_TILE_ORDER 25    /* pw_expand4_v2_kernel: which 64-state tiles a wavefront takes: 0 interleaved over the workgroups,
                                       1 XCD x (workgroup index mod 8) sweeps the x-th contiguous eighth of the frontier; + 2: plain
                                       instead of non-temporal stores (A/B measurements only) */
-#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: -1 / 2 (the default) software pipeline -- a tile's successors stay staged in
+#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: 2 (and -1, the default, beyond 8 movables) software pipeline -- a tile's successors stay staged in
                                       LDS and leave, as non-temporal whole-line stores, after the NEXT tile's parent rows have been
                                       requested; 0 a tile loads its rows at its top and stores at its end (also what runs where the
                                       pipeline's staging does not fit in 80 KB of LDS) */
-#define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU (0 = automatic: 8; those that do not fit at
-                                      once queue up behind the others) */
+#define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU, 1 .. 64 (0 = automatic: up to 8 movables one workgroup
+                                      per 4 tiles of 64 states -- 8 tiles at 7 and 8 movables -- whatever the frontier's size; 8 per CU beyond) */
 #define PW_OPT_SEARCH_BATCH_GROUPS_PER_CU 28 /* pw_search_batch: persistent workgroups per CU (0 = automatic) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);

@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from tools import config_suite as cs  # noqa: E402
 
 
+GROUPS = tuple(int(v) for v in next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--gp=")), "2,3,4,8").split(","))
+
+
 def main():
     puzzles = [a for a in sys.argv[1:] if not a.startswith("--")] or ["level1/2 Obstacle.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp", "level3/Armor.pwp",
                                "level1/Pull Up.pwp"]
@@ -24,11 +27,12 @@ def main():
         sets = [(torch.as_tensor(st_host).to(dev), torch.empty((F, 4, N), dtype=torch.int32, device=dev),
                  torch.empty((F, 4), dtype=torch.int32, device=dev), torch.empty((F, 4), dtype=torch.uint8, device=dev)) for _ in range(nbuf)]
         ref = None
-        variants = [("v1 (tables through L1)", {"expand_lds_tables": 2})]
-        orders = (0, 1, 2) if "--orders" in sys.argv else (0, 2)  # (2: plain stores instead of non-temporal ones)
+        quick = "--quick" in sys.argv  # only the non-temporal-store kernels, no v1
+        variants = [] if quick else [("v1 (tables through L1)", {"expand_lds_tables": 2})]
+        orders = (0,) if quick else ((0, 1, 2) if "--orders" in sys.argv else (0, 2))  # (2: plain stores instead of non-temporal ones)
         for order in orders:
-            for pre in (-1, 0, 2):  # 0: stores at the end of a tile (kPipe 0), 2: one tile late (kPipe 1)
-                for gp in ((0,) if pre < 0 else (2, 3, 4, 8)):
+            for pre in ((0, 2) if quick else (-1, 0, 2)):  # 0: stores at the end of a tile (kPipe 0), 2: one tile late (kPipe 1)
+                for gp in ((0,) if pre < 0 else GROUPS):
                     variants.append((f"v2 order {order} prefetch {'auto' if pre < 0 else pre} groups/CU {gp or 'auto'}",
                                      {"expand_lds_tables": 0, "expand_tile_order": order, "expand_prefetch": pre, "expand_groups_per_cu": gp}))
         for name, opts in variants:
