@@ -268,7 +268,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_STEP_BOARD_SET 23     /* read-only: 1 when the engine's set qualifies for PW_OPT_STEP_BOARDS */
 #define PW_OPT_EXPAND_LDS_TABLES 24  /* pw_expand4 with one lane per state: 0 (default) the kernel that keeps the puzzle's push tables in
                                       LDS (pw_expand4_v2_kernel: 2 .. 16 movables, tables up to 48 KB, 16-byte aligned output
-                                      buffers) wherever it applies, 2 never (tables read from HBM through L1) */
+                                      buffers) wherever it applies, 2 never (pw_expand4_lane_kernel: tables read from HBM through L1, round 3's
+                                      staging of 1 / 2 actions at a time), 3 never + all four actions staged at once and non-temporal
+                                      stores (what that kernel does by itself up to 14 movables when option 0 sends a launch to it) */
 #define PW_OPT_EXPAND_TILE_ORDER 25    /* pw_expand4_v2_kernel: which 64-state tiles a wavefront takes: 0 interleaved over the workgroups,
                                       1 XCD x (workgroup index mod 8) sweeps the x-th contiguous eighth of the frontier; + 2: plain
                                       instead of non-temporal stores (A/B measurements only) */

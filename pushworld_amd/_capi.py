@@ -183,7 +183,7 @@ OPTIONS = {
     "step_block_order": 20,    # 0 / "forward", 1 / "reverse": which end of the batch the step kernel starts with
     "step_boards": 22,         # sets of 8 x 8 puzzles, state only: 0 / "auto" whole-grid boards in registers, 2 / "never"
     "step_board_set": 23,      # read-only: the set qualifies
-    "expand_lds_tables": 24,   # pw_expand4, one lane per state: 0 / "auto" push tables in LDS where they fit, 2 / "never"
+    "expand_lds_tables": 24,   # pw_expand4, one lane per state: 0 / "auto" push tables in LDS where they fit, 2 / "never", 3 never + whole runs
     "expand_tile_order": 25,   # pw_expand4_v2_kernel: 0 tiles interleaved, 1 a contiguous eighth of the frontier per XCD
     "expand_prefetch": 26,     # ... 1 = next tile's rows in flight while this one is computed
     "search_batch_groups_per_cu": 28,  # pw_search_batch: persistent workgroups per CU (0 = automatic)

@@ -71,6 +71,12 @@ def bfs(puzzle, max_states):
     "cpptest:necessary_transitive_pushing3.pwp|lanes-hbm", "cpptest:multiple_goals.pwp|lanes-hbm",
     "bench:level1/2 Obstacle.pwp|lanes-hbm", "bench:level2/Pull Dont Push.pwp|lanes-hbm", "bench:level4/Four Pistons.pwp|lanes-hbm",
     "bench:level3/Armor.pwp|lanes-hbm", "bench:level1/A Tight Squeeze.pwp|lanes-hbm",
+    # "lanes-hbm-runs": that kernel with all four actions staged at once and non-temporal stores (what it does by itself up to
+    # 14 movables wherever the LDS kernel does not apply: tables beyond 48 KB, unaligned buffers), forced for every N
+    "cpptest:multiple_goals.pwp|lanes-hbm-runs", "bench:level1/2 Obstacle.pwp|lanes-hbm-runs", "bench:level2/Pull Dont Push.pwp|lanes-hbm-runs",
+    "bench:level4/Four Pistons.pwp|lanes-hbm-runs", "bench:level3/Armor.pwp|lanes-hbm-runs", "bench:level1/A Tight Squeeze.pwp|lanes-hbm-runs",
+    "bench:level1/Pull Up.pwp|lanes-hbm-runs", "bench:level4/Pinhole Lock.pwp|lanes-hbm-runs", "bench:level3/Chain Link Tunnel.pwp|lanes-hbm-runs",
+    "bench:level2/Simultaneous Obstacle Removal.pwp|lanes-hbm-runs", "bench:level2/Clean Sweep.pwp|lanes-hbm-runs",
     # more movable counts for the LDS kernel's per-N instances (5, 8, 9, 10, 11, 14 ...)
     # every movable count the LDS kernel is instantiated for: 4 .. 16 (2, 3, 6, 7, 12 are above)
     "bench:level1/At Crossroads.pwp|lanes", "bench:level1/Building Blocks.pwp|lanes", "bench:level1/Pull Up.pwp|lanes",
@@ -91,9 +97,9 @@ def test_bfs_layers_match_oracle(golden, key):
     pz = PushWorldPuzzle(text=text, order="cpp")
     if tables == "wide":
         pz._engine().set_option("step_wide_groups", 1)
-    elif tables in ("lanes", "lanes-hbm"):
+    elif tables in ("lanes", "lanes-hbm", "lanes-hbm-runs"):
         pz._engine().set_option("step_kernel", "lane")
-        pz._engine().set_option("expand_lds_tables", "never" if tables == "lanes-hbm" else "auto")
+        pz._engine().set_option("expand_lds_tables", {"lanes": "auto", "lanes-hbm": "never", "lanes-hbm-runs": 3}[tables])
     elif tables:
         pz._engine().set_option("step_tables", tables)
         assert (pz._engine().get_option("step_table_puzzles") == 1) == (tables == "all")

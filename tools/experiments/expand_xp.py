@@ -29,8 +29,10 @@ def main():
         ref = None
         quick = "--quick" in sys.argv  # only the non-temporal-store kernels, no v1
         variants = [] if quick else [("v1 (tables through L1)", {"expand_lds_tables": 2})]
+        if "--v1runs" in sys.argv:
+            variants = [("v1 (tables through L1)", {"expand_lds_tables": 2}), ("v1, all four actions per pass, non-temporal", {"expand_lds_tables": 3})]
         orders = (0,) if quick else ((0, 1, 2) if "--orders" in sys.argv else (0, 2))  # (2: plain stores instead of non-temporal ones)
-        for order in orders:
+        for order in (() if "--v1runs" in sys.argv else orders):
             for pre in ((0, 2) if quick else (-1, 0, 2)):  # 0: stores at the end of a tile (kPipe 0), 2: one tile late (kPipe 1)
                 for gp in ((0,) if pre < 0 else GROUPS):
                     variants.append((f"v2 order {order} prefetch {'auto' if pre < 0 else pre} groups/CU {gp or 'auto'}",
