@@ -267,19 +267,20 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       0 (default) automatic, 2 never (the lane groups) */
 #define PW_OPT_STEP_BOARD_SET 23     /* read-only: 1 when the engine's set qualifies for PW_OPT_STEP_BOARDS */
 #define PW_OPT_EXPAND_LDS_TABLES 24  /* pw_expand4 with one lane per state: 0 (default) the kernel that keeps the puzzle's push tables in
-                                      LDS (pw_expand4_v2_kernel: 2 .. 16 movables, tables up to 48 KB, 16-byte aligned output
+                                      LDS (pw_expand4_v2_kernel: 2 .. 16 movables, tables up to 112 KB, 16-byte aligned output
                                       buffers) wherever it applies, 2 never (pw_expand4_lane_kernel: tables read from HBM through L1, round 3's
                                       staging of 1 / 2 actions at a time), 3 never + all four actions staged at once and non-temporal
                                       stores (what that kernel does by itself up to 14 movables when option 0 sends a launch to it) */
 #define PW_OPT_EXPAND_TILE_ORDER 25    /* pw_expand4_v2_kernel: which 64-state tiles a wavefront takes: 0 interleaved over the workgroups,
                                       1 XCD x (workgroup index mod 8) sweeps the x-th contiguous eighth of the frontier; + 2: plain
                                       instead of non-temporal stores (A/B measurements only) */
-#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: 2 (and -1, the default, beyond 8 movables) software pipeline -- a tile's successors stay staged in
+#define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: 2 (and -1, the default, for persistent workgroups) software pipeline -- a tile's successors stay staged in
                                       LDS and leave, as non-temporal whole-line stores, after the NEXT tile's parent rows have been
                                       requested; 0 a tile loads its rows at its top and stores at its end (also what runs where the
                                       pipeline's staging does not fit in 80 KB of LDS) */
-#define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU, 1 .. 64 (0 = automatic: up to 8 movables one workgroup
-                                      per 4 tiles of 64 states -- 8 tiles at 7 and 8 movables -- whatever the frontier's size; 8 per CU beyond) */
+#define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU, 1 .. 64 (0 = automatic: with small tables and up to 8
+                                      movables one workgroup per 4 tiles of 64 states -- 8 tiles at 7 and 8 movables -- whatever the
+                                      frontier's size; else 8 per CU, or what is resident (at most 2) with tables beyond 32 KB) */
 #define PW_OPT_SEARCH_BATCH_GROUPS_PER_CU 28 /* pw_search_batch: persistent workgroups per CU (0 = automatic) */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);

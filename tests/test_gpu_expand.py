@@ -65,14 +65,18 @@ def bfs(puzzle, max_states):
     "bench:level3/Armor.pwp|lanes", "bench:level3/Rocky Shore.pwp|lanes", "bench:level2/Bubbles.pwp|lanes",
     "bench:level3/Moving Mountains.pwp|lanes", "bench:level1/A Tight Squeeze.pwp|lanes",  # (N = 2: rows of one word)
     "bench:level2/Clean Sweep.pwp|lanes",  # 19 movables: the instance with 32 bits per action
-    # "lanes" runs pw_expand4_v2_kernel (push tables in LDS) wherever it applies -- 2 .. 16 movables, tables up to 48 KB --;
+    # "lanes" runs pw_expand4_v2_kernel (push tables in LDS) wherever it applies -- 2 .. 16 movables, tables up to 112 KB --;
     # "lanes-hbm": pw_expand4_lane_kernel (tables read through L1) for the same puzzles
     "cpptest:trivial_tool2.pwp|lanes-hbm", "cpptest:blocked_transitive_pushing2.pwp|lanes-hbm",
     "cpptest:necessary_transitive_pushing3.pwp|lanes-hbm", "cpptest:multiple_goals.pwp|lanes-hbm",
     "bench:level1/2 Obstacle.pwp|lanes-hbm", "bench:level2/Pull Dont Push.pwp|lanes-hbm", "bench:level4/Four Pistons.pwp|lanes-hbm",
     "bench:level3/Armor.pwp|lanes-hbm", "bench:level1/A Tight Squeeze.pwp|lanes-hbm",
+    # tables of 50 .. 103 KB in LDS (one or two workgroups per CU)
+    "bench:level3/Caged Key.pwp|lanes", "bench:level3/Crow Pulling.pwp|lanes", "bench:level2/Lock And Load.pwp|lanes",
+    "bench:level1/Pulling.pwp|lanes", "bench:level3/Put Away Toys.pwp|lanes", "bench:level2/Encircle.pwp|lanes",
+    "bench:level4/Pinhole Lock.pwp|lanes",
     # "lanes-hbm-runs": that kernel with all four actions staged at once and non-temporal stores (what it does by itself up to
-    # 14 movables wherever the LDS kernel does not apply: tables beyond 48 KB, unaligned buffers), forced for every N
+    # 14 movables wherever the LDS kernel does not apply: tables beyond 112 KB, unaligned buffers), forced for every N
     "cpptest:multiple_goals.pwp|lanes-hbm-runs", "bench:level1/2 Obstacle.pwp|lanes-hbm-runs", "bench:level2/Pull Dont Push.pwp|lanes-hbm-runs",
     "bench:level4/Four Pistons.pwp|lanes-hbm-runs", "bench:level3/Armor.pwp|lanes-hbm-runs", "bench:level1/A Tight Squeeze.pwp|lanes-hbm-runs",
     "bench:level1/Pull Up.pwp|lanes-hbm-runs", "bench:level4/Pinhole Lock.pwp|lanes-hbm-runs", "bench:level3/Chain Link Tunnel.pwp|lanes-hbm-runs",
