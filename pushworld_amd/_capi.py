@@ -186,6 +186,7 @@ OPTIONS = {
     "expand_lds_tables": 24,   # pw_expand4, one lane per state: 0 / "auto" push tables in LDS where they fit, 2 / "never", 3 never + whole runs
     "expand_tile_order": 25,   # pw_expand4_v2_kernel: 0 tiles interleaved, 1 a contiguous eighth of the frontier per XCD
     "expand_prefetch": 26,     # ... 1 = next tile's rows in flight while this one is computed
+    "expand_wg_waves": 29,  # pw_expand4 with one (large-table) workgroup per CU: cap on its wavefronts (0 automatic)
     "search_batch_groups_per_cu": 28,  # pw_search_batch: persistent workgroups per CU (0 = automatic)
     "expand_groups_per_cu": 27,  # ... persistent workgroups per CU (0 = automatic)
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")

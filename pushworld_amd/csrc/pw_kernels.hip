@@ -132,6 +132,7 @@ struct PwEngine {
   int expand_lds_tables;   // PW_OPT_EXPAND_LDS_TABLES: 0 automatic (pw_expand4_v2_kernel where the tables fit LDS), 2 never
   int expand_tile_order;   // PW_OPT_EXPAND_TILE_ORDER: pw_expand4_v2_kernel: 0 tiles interleaved, 1 a contiguous eighth per XCD
   int expand_prefetch;     // PW_OPT_EXPAND_PREFETCH: ... loads the next tile's rows while it computes this one
+  int expand_wg_waves;  // PW_OPT_EXPAND_WG_WAVES: cap on the wavefronts of a lone workgroup per CU (0 = automatic)
   int search_batch_groups_per_cu;  // PW_OPT_SEARCH_BATCH_GROUPS_PER_CU (0 = automatic)
   int expand_groups_per_cu;  // PW_OPT_EXPAND_GROUPS_PER_CU: persistent workgroups per CU (0 = as many as fit LDS, at most 8)
   int64_t ovl_bytes;

@@ -32,7 +32,10 @@ def main():
         if "--v1runs" in sys.argv:
             variants = [("v1 (tables through L1)", {"expand_lds_tables": 2}), ("v1, all four actions per pass, non-temporal", {"expand_lds_tables": 3})]
         orders = (0,) if quick else ((0, 1, 2) if "--orders" in sys.argv else (0, 2))  # (2: plain stores instead of non-temporal ones)
-        for order in (() if "--v1runs" in sys.argv else orders):
+        if "--wgwaves" in sys.argv:  # lone workgroups per CU (tables beyond ~70 KB): wavefronts per workgroup
+            variants = [(f"v2 automatic, at most {w or 8} wavefronts per workgroup", {"expand_lds_tables": 0, "expand_tile_order": 0, "expand_prefetch": -1,
+                                                                                 "expand_groups_per_cu": 0, "expand_wg_waves": w}) for w in (4, 0)]
+        for order in (() if ("--v1runs" in sys.argv or "--wgwaves" in sys.argv) else orders):
             for pre in ((0, 2) if quick else (-1, 0, 2)):  # 0: stores at the end of a tile (kPipe 0), 2: one tile late (kPipe 1)
                 for gp in ((0,) if pre < 0 else GROUPS):
                     variants.append((f"v2 order {order} prefetch {'auto' if pre < 0 else pre} groups/CU {gp or 'auto'}",
