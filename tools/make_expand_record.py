@@ -15,7 +15,7 @@ def main():
     benches = sys.argv[1:] or [os.path.join(P, "r04_bench.json")]
     pm = json.load(open(os.path.join(P, "pmc_kernels_latest.json")))
     out = ["# pw_expand4 (C5) with the round's final kernel -- pw_expand4_v2_kernel<N, 1, true>: push tables in LDS, whole-line staging,",
-           "# non-temporal stores issued one tile late, 8 persistent workgroups per CU, 24-bit arithmetic -- on 4 M-state frontiers cycling",
+           "# non-temporal stores, one tile per wavefront up to 8 movables / 8 persistent workgroups per CU and a store pipeline beyond, 24-bit arithmetic -- 4 M-state frontiers cycling",
            "# through > 640 MB of buffers (beyond the 256 MB Infinity Cache; `2 Obstacle` has 39 023 reachable states: tiled to 4 M rows, the",
            "# two others are 4 M DISTINCT states).  Algorithmic bytes per parent 20 N + 20.  peak = 8 TB/s.",
            "# (The kernel's first version: r04_expand4_first_version.txt; every variant and session: r04_expand4_variants.txt.)", "#"]
