@@ -657,6 +657,16 @@ class Engine:
         view = storage.as_strided((batch, h, w, c), (self.obs_stride // esz, w * c, c, 1))
         return storage, view
 
+    def alloc_obs_host(self, batch: int):
+        """``alloc_obs`` in pinned host memory (hipHostMalloc: mapped into the device's address space at the same address):
+        the render kernels write it over PCIe, the host reads it without a copy command.  For the single-environment
+        adapters -- a batch of thousands belongs in HBM."""
+        esz = 1 if self.obs_dtype == torch.uint8 else 4
+        storage = torch.zeros((batch, self.obs_stride // esz), dtype=self.obs_dtype).pin_memory()
+        h, w, c = self.obs_shape
+        view = storage.as_strided((batch, h, w, c), (self.obs_stride // esz, w * c, c, 1))
+        return storage, view
+
     def _wrap_owned(self, ptr: int, batch: int):
         """(storage, view) tensors over a library-owned buffer; the memory goes back to the DEVICE (``pw_obs_free``)
         when the last tensor over it has gone."""
