@@ -87,6 +87,12 @@ class SingleEnvCore:
         self._obs_storage, self._obs = self._engine.alloc_obs_host(1)
         self.obs_shape = self._engine.obs_shape
         self._raw_host = torch.zeros_like(self._raw, device="cpu").pin_memory()
+        # the step's pointers never change: marshalled once (the action is a byte of self._acts)
+        b = self._buf
+        self._step_call = self._engine.bind_step_render(self._pid, b["pos"], b["steps"], b["reward"], b["dgoals"], b["terminated"],
+                                                        b["truncated"], self._obs_storage, 0, delta=True)
+        self._acts_ptr = self._acts.data_ptr()
+        self._stream = torch.cuda.current_stream(dev_t)
 
     # ------------------------------------------------------------------
     def _read_back(self):
@@ -113,11 +119,11 @@ class SingleEnvCore:
         """Returns (observation, reward: float, terminated: bool, truncated: bool)."""
         if self._current_state is None:
             raise RuntimeError("reset() must be called before step() can be called.")
-        b = self._buf
-        act = self._acts[int(action):int(action) + 1]
-        # the observation buffer is this environment's own and always current: incremental redraw
-        self._engine.step_render_delta(self._pid, act, b["pos"], b["steps"], b["reward"], b["dgoals"],
-                                       b["terminated"], b["truncated"], self._obs_storage)
+        action = int(action)
+        if not 0 <= action <= 3:  # (the adapters have checked their action spaces; the pointer arithmetic below must not run wild)
+            raise ValueError("The provided action is not in the action space.")
+        # the observation buffer is this environment's own and always current: incremental redraw (pw_step_render_delta)
+        self._step_call(self._acts_ptr + action)
         observation, raw = self._read_back()
         self._steps += 1
         n = self._current_puzzle.num_movables
