@@ -277,7 +277,7 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_EXPAND_PREFETCH 26      /* pw_expand4_v2_kernel: 2 (and -1, the default, for persistent workgroups) software pipeline -- a tile's successors stay staged in
                                       LDS and leave, as non-temporal whole-line stores, after the NEXT tile's parent rows have been
                                       requested; 0 a tile loads its rows at its top and stores at its end (also what runs where the
-                                      pipeline's staging does not fit in 80 KB of LDS) */
+                                      pipeline's staging does not fit in 78 KB of LDS) */
 #define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU, 1 .. 64 (0 = automatic: with small tables and up to 8
                                       movables one workgroup per 4 tiles of 64 states -- 8 tiles at 7 and 8 movables -- whatever the
                                       frontier's size; else 8 per CU, or what is resident (at most 2) with tables beyond 32 KB) */
