@@ -281,6 +281,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_EXPAND_GROUPS_PER_CU 27 /* pw_expand4_v2_kernel: persistent workgroups per CU, 1 .. 64 (0 = automatic: with small tables and up to 8
                                       movables one workgroup per 4 tiles of 64 states -- 8 tiles at 7 and 8 movables -- whatever the
                                       frontier's size; else 8 per CU, or what is resident (at most 2) with tables beyond 32 KB) */
+#define PW_OPT_STEP_MIXED_GROUPS 30 /* N_pad 8 / 16 sets with overlap tables for every puzzle: 0 (default) the lanes per environment are chosen per
+                                      workgroup of 32 environments (4 / 8 / 8 with two movables per lane), 2 never (one choice per set) */
 #define PW_OPT_EXPAND_WG_WAVES 29 /* pw_expand4_v2_kernel with tables so large that one workgroup fits a CU: 4 or 8 wavefronts per workgroup (0 = automatic: 8
                                     where its LDS has staging room for them) */
 #define PW_OPT_SEARCH_BATCH_GROUPS_PER_CU 28 /* pw_search_batch: persistent workgroups per CU (0 = automatic) */

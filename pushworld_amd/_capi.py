@@ -186,6 +186,7 @@ OPTIONS = {
     "expand_lds_tables": 24,   # pw_expand4, one lane per state: 0 / "auto" push tables in LDS where they fit, 2 / "never", 3 never + whole runs
     "expand_tile_order": 25,   # pw_expand4_v2_kernel: 0 tiles interleaved, 1 a contiguous eighth of the frontier per XCD
     "expand_prefetch": 26,     # ... 1 = next tile's rows in flight while this one is computed
+    "step_mixed_groups": 30,  # N_pad 8 / 16 sets with tables: lanes per environment chosen per workgroup (0 auto, 2 never)
     "expand_wg_waves": 29,  # pw_expand4 with one (large-table) workgroup per CU: cap on its wavefronts (0 automatic)
     "search_batch_groups_per_cu": 28,  # pw_search_batch: persistent workgroups per CU (0 = automatic)
     "expand_groups_per_cu": 27,  # ... persistent workgroups per CU (0 = automatic)
@@ -199,6 +200,7 @@ _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds":
 _OPTION_VALUES_BY_KEY = {"step_boards": {"auto": 0, "never": 2},
                          "step_narrow_groups": {"auto": 0, "always": 1, "never": 2},
                          "expand_lds_tables": {"auto": 0, "never": 2},
+                         "step_mixed_groups": {"auto": 0, "never": 2},
                          "step_lds_tables": {"auto": 0, "always": 1, "never": 2}}
 
 

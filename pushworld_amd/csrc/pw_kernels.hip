@@ -112,6 +112,7 @@ struct PwEngine {
   bool force_lds_render;   // PW_OPT_RENDER_KERNEL = 1: per-environment LDS kernel even where the page kernel applies
   int64_t page_slice_envs; // PW_OPT_PAGE_SLICE_ENVS: environments per page-kernel launch (0 = what 2^31 chunks allow)
   int64_t search_chunk;    // PW_OPT_SEARCH_CHUNK: parents per pw_search_expand pass (0 = 2^20)
+  int step_mixed;          // PW_OPT_STEP_MIXED_GROUPS: lanes per environment chosen per workgroup on N_pad 8 / 16 sets (0 auto, 2 never)
   int step_wide_groups;    // PW_OPT_STEP_WIDE_GROUPS: 32 lanes per environment for N_pad 32 instead of two movables per lane
   int64_t step_lane_batch; // PW_OPT_STEP_LANE_BATCH: state-only launches from this batch size on run one lane per environment
   int step_reverse;        // PW_OPT_STEP_BLOCK_ORDER: the lane-group step kernels start with the LAST environments
