@@ -60,8 +60,8 @@ python tools/make_kernel_pmc_record.py "tools/collect_profiles.sh $TAG" \
   "C3_f32_ppc3:pw_render_page_kernel<float:65536:$P/c3f3_fetch_results.db:$P/c3f3_write_results.db" \
   "C3_f32_ppc20_8192:pw_render_rowpage_kernel<float:8192:$P/c3f20_fetch_results.db:$P/c3f20_write_results.db::3" \
   "C4_u8_ppc3:pw_render_page_kernel<unsigned char:65536:$P/c4u8_fetch_results.db:$P/c4u8_write_results.db" \
-  "C4_state:pw_step_group_mixed_kernel<true>:65536:$P/c4_fetch_results.db:$P/c4_write_results.db" \
-  "C4_rollout:pw_step_group_mixed_kernel<false>:4194304:$P/c4_fetch_results.db:$P/c4_write_results.db" \
+  "C4_state:pw_step_group_mixed_kernel<true,:65536:$P/c4_fetch_results.db:$P/c4_write_results.db" \
+  "C4_rollout:pw_step_group_mixed_kernel<false,:4194304:$P/c4_fetch_results.db:$P/c4_write_results.db" \
   "C2_step:pw_step_board_kernel:4096:$P/c2s_fetch_results.db:$P/c2s_write_results.db" \
   "C2_rollout:pw_step_board_kernel:262144:$P/c2r_fetch_results.db:$P/c2r_write_results.db" \
   "C5_2_obstacle:pw_expand4_v2_kernel<3,:4000000:$P/x2ob_fetch_results.db:$P/x2ob_write_results.db" \
