@@ -257,8 +257,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       environment (the table-only formulation, 64 environments per wavefront: ~3x fewer
                                       instructions per environment than a lane group, but an eighth of the wavefronts -- it wins
                                       once the batch alone fills the chip; needs overlap tables for every puzzle of the set).
-                                      0 = default (131 072 for sets with up to 16 movables per puzzle; N_pad 32 sets: 327 680 for
-                                      one step per launch, 1 048 576 for pw_rollout); a threshold no batch reaches (2^31) = never.
+                                      0 = default (sets with up to 16 movables per puzzle: 131 072 for one step per launch, 196 608
+                                      for pw_rollout; N_pad 32 sets: 327 680 and 2 097 152); a threshold no batch reaches (2^31) = never.
                                       Also the number of states from which pw_expand4 and the passes of pw_search_expand run one
                                       lane per state (default 131 072; PW_OPT_STEP_KERNEL lane forces it for every size) */
 #define PW_OPT_STEP_BOARDS 22        /* sets whose puzzles ALL fit into 8 x 8 cells (grid with its border walls: the 5 x 5 Level-0
