@@ -133,19 +133,23 @@ def run_c1(cpu=True):
         for a in acts[:100]:
             env.step(int(a))
         env.reset(seed=0)
-        m = 3000
-        t0 = time.perf_counter()
-        for a in acts[:m]:
-            _, _, term, trunc, _ = env.step(int(a))
-            if term or trunc:
-                env.reset()
-        dt = time.perf_counter() - t0
+        m = 1500
+        rates = []  # three segments: a host-side latency loop -- the boxes' CPUs are shared, one busy neighbour halves a segment
+        for seg in range(3):
+            t0 = time.perf_counter()
+            for a in acts[seg * m:(seg + 1) * m]:
+                _, _, term, trunc, _ = env.step(int(a))
+                if term or trunc:
+                    env.reset()
+            rates.append(m / (time.perf_counter() - t0))
+        dt = m / max(rates)
         eng = env._engine
         b = env._buf
         ms = launch_ms(eng, lambda: eng.render(env._pid, b["pos"], env._obs_storage), 200)
         out["gym_step_with_render"] = entry(
             m / dt, "env-steps/s", "gym PushWorldEnv.step (+ reset on done), default ppc 20 / border 2 / float32 observation returned as a host array",
-            eng.render_kernel, int(eng.obs_bytes), 1, ms, obs_shape=list(env.observation_space.shape),
+            eng.render_kernel, int(eng.obs_bytes), 1, ms, obs_shape=list(env.observation_space.shape), samples=rates,
+            sample="best of 3 segments of 1 500 steps (all three in `samples`)",
             note="batch 1 is launch / copy latency, not bandwidth: the fraction is reported because every entry has one")
         pz = PushWorldPuzzle(path)
         s = pz.initial_state
