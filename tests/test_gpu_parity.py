@@ -53,6 +53,8 @@ def _step_options(kernel):
     overlap tables (PW_OPT_STEP_TABLES) for every puzzle / for none (default: for puzzles with movables beyond 8 x 8)."""
     if kernel == "group-narrow":  # N_pad 16 pools: 8 lanes per environment, two movables per lane
         return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 1}
+    if kernel == "group-unmixed":  # N_pad 8 / 16 pools: ONE choice of lanes for the whole set (default: per workgroup of 32 environments)
+        return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_mixed_groups": "never"}
     if kernel == "group-16lanes":  # N_pad 32 pools: 16-lane groups for every environment (default: 8-lane groups where N <= 16)
         return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 2}
     if kernel == "group-tables":
@@ -84,6 +86,7 @@ def _step_options(kernel):
                                           ("bench", "group-notables"), ("tests", "group-notables"),
                                           ("bench", "group-bigtables"), ("bench", "group-bigtables-lds"),
                                           ("level1", "group"), ("level1", "group-narrow"), ("level1", "group-lds"),
+                                          ("level1", "group-unmixed"), ("l0", "group-unmixed"), ("tests", "group-unmixed"),
                                           ("bench", "lane"), ("tests", "lane"), ("l0", "lane"), ("level1", "lane"),
                                           ("bench", "lane-notables"), ("tests", "lane-notables"),
                                           ("bench", "big-batch"), ("l0", "big-batch"),
