@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 ``--gpus N`` without a torchrun environment re-executes itself through ``torch.distributed.run`` with N
-ranks (one process per GPU, RCCL over xGMI for the timing barrier and ONE counter reduction); it exits
-non-zero when fewer than N devices are visible instead of quietly measuring one.
+ranks (one process per GPU; RCCL over xGMI carries NO data-path traffic, only: one probe all_reduce at start-up, two
+barriers per timed window and, once after the last window, all_reduce(SUM) of the device counter vector, all_reduce(MAX) of
+the window times and two small all_gathers of per-rank report rows); it exits non-zero when fewer than N devices are
+visible, or when the probe all_reduce does not see N ranks, instead of quietly measuring fewer.
 
 Workloads (``BASELINE.json`` / SURVEY 8d), per GPU:
   c3 (default, the headline)  65 536 environments over the 68 Level-1 puzzles (sorted by file name,
@@ -23,14 +25,16 @@ Timing: ``--windows`` windows of EXACTLY K steps each, every window bracketed by
 sides, per window the MAX over ranks; ``ms_per_step`` / ``value`` are the MEDIAN window (min / max reported too:
 one 14 ms window is inside the +-3 % spread between observation-buffer allocations).
 
-One JSON line is printed by rank 0 (contract in the task statement) with two extra objects: ``roofline`` for
+One JSON line of at most 4 KB is printed by rank 0 (contract in the task statement; tools/bench_line.py: top-level contract
+fields + ``config`` + ``roofline`` + ``cpu_baseline`` + one short object per other configuration); the FULL record (every
+sample, window, tuner candidate, sample description) goes to ``gpurun_out/bench_full.json``.  Two extra objects: ``roofline`` for
 the dominant kernel (render; HBM bound), timed live by HIP events the library records around that launch on
 the launch stream (``PW_OPT_PROFILE_RENDER``), and ``cpu_baseline`` = the C restatement of the reference
 algorithm (oracle/pw_oracle.c, kind "port") timed on this host's cores on a bounded sample (pinned OpenMP threads, best
 of three samples, all three reported), with 1 thread and with all threads, plus the pure-Python restatement of the
 reference environment (the reference's own Python env cannot travel to the GPU box) on 1 core and on P processes.
-``counters`` is the vector the step kernels keep on the device (pw_counters), summed over ranks by the job's one
-all_reduce.  ``configs`` (N = 1, c3 line; ``--no-configs`` drops it) puts every other BASELINE.json configuration on the
+``counters`` is the vector the step kernels keep on the device (pw_counters), summed over ranks by the job's
+all_reduce(SUM).  ``configs`` (N = 1, c3 line; ``--no-configs`` drops it) puts every other BASELINE.json configuration on the
 same clock (tools/config_suite.py): C1, C2, C3 float32 ppc 3 / ppc 20, C4 state-only + uint8, C5 on three puzzles, each
 with its dominant kernel's launch time, roofline fraction, PMC traffic record and its own CPU baseline.  Non-headline
 extras (``--no-extras`` drops them): ``incremental_render`` (the persistent observation buffer maintained by
@@ -191,7 +195,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of --steps steps each (median reported); 0 = as many as fill --min-seconds, at least 7")
-    ap.add_argument("--min-seconds", type=float, default=5.0,
+    ap.add_argument("--min-seconds", type=float, default=3.0,
                     help="with --windows 0: total timed GPU work (long enough for a device-utilisation sampler to see it)")
     ap.add_argument("--config", choices=["c3", "c4"], default="c3")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
@@ -201,7 +205,7 @@ def main():
                     help="default: uint8 for c3, none (state only) for c4")
     ap.add_argument("--max-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=3.0,
+    ap.add_argument("--cpu-seconds", type=float, default=2.0,
                     help="CPU work of ONE all-threads C-port sample (three are taken, the best is the value; the other CPU "
                          "samples scale with it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the incremental-render / rollout extras")
@@ -217,6 +221,8 @@ def main():
     ap.add_argument("--tune-allocations", type=int, default=None,
                     help="at most this many candidate allocations of the library-owned observation buffer (pw_obs_alloc_tuned "
                          "keeps the first one of the fast class); default: the product default of VecPushWorld")
+    ap.add_argument("--full-record", default=None,
+                    help="where the full record goes (default gpurun_out/bench_full.json, bench_full_n<N>.json for N > 1)")
     args = ap.parse_args()
     if args.obs is None:
         args.obs = "uint8" if args.config == "c3" else "none"
@@ -244,6 +250,7 @@ def main():
     torch.cuda.set_device(device_index)
     dist = None
     backend = None
+    probe_ranks = None
     # BENCH_FORCE_DIST=1: take the collective path even with one rank (smoke test of the N > 1 plumbing)
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist  # RCCL over xGMI; used only for the timing barrier / reductions
@@ -261,7 +268,8 @@ def main():
                 probe = torch.ones(1, device=torch.device("cuda", device_index))
                 dist.all_reduce(probe)  # the first collective creates the RCCL communicator: fail here, loudly
                 torch.cuda.synchronize()
-                if int(probe.item()) != world:
+                probe_ranks = int(probe.item())
+                if probe_ranks != world:
                     raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
         except Exception as exc:  # noqa: BLE001 -- never fall back to fewer ranks or another backend
             print(f"bench.py: rank {rank}: torch.distributed ({backend}) failed: {exc!r}", file=sys.stderr, flush=True)
@@ -419,6 +427,8 @@ def main():
             "n_pad": n_obj,
             "parallelism": f"env-sharded x{world}, no data-path collective"
                            + (f" (counters over {backend})" if backend else ""),
+            # how many ranks RCCL's start-up all_reduce of ones summed to (None: no process group, N = 1)
+            "ranks_in_probe_all_reduce": probe_ranks,
             # launch configuration of the page-ordered render kernel on rank 0 (pw_engine_tune_render at the first
             # reset: same bytes, the fastest of 16 page orders / occupancies for THIS observation buffer)
             "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
@@ -489,6 +499,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy_6290": achieved / 6290.0,
+            # the MEASURED fraction: recorded PMC traffic of this launch / its duration here / the peak
+            "hbm_frac": (traffic / render_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "traffic_ratio": (traffic / algo) if traffic else None,
             "traffic": traffic,
             "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": algo,
@@ -595,8 +608,8 @@ def main():
                                           "steps_per_launch": Tn, "envs": B, "n_gpus": 1}
         except Exception as exc:  # noqa: BLE001
             out["state_only_rollout"] = {"error": repr(exc)}
-    if not args.no_cpu_baseline:
-        # rank 0's host cores, also for N > 1 (the other ranks have finished; their processes are idle or gone)
+    if not args.no_cpu_baseline and world == 1:
+        # rank 0's host cores, N = 1 only (the contract: the CPU figure belongs to the single-GPU line)
         fh, fw = eng.obs_shape[0] // args.ppc, eng.obs_shape[1] // args.ppc
         torch.cuda.synchronize()
         time.sleep(2.0)  # the host has been feeding launches: let it settle before the CPU samples
@@ -625,7 +638,21 @@ def main():
                                         "avg_launch_ms": out["roofline"]["avg_launch_ms"], "traffic": out["roofline"]["traffic"],
                                         "algorithmic_bytes_per_unit": out["roofline"]["algorithmic_bytes_per_launch"] // B}
         out["configs_wall_s"] = time.perf_counter() - t_cfg
-    print(json.dumps(out), flush=True)
+    # the FULL record to a side file (and nothing of it to stdout: the driver keeps only the tail of stdout), the compact line
+    # of at most 4 KB to stdout
+    from tools.bench_line import MAX_LINE_BYTES, compact_line, dumps
+    full_path = args.full_record or os.path.join("gpurun_out", "bench_full.json" if world == 1 else f"bench_full_n{world}.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.join(ROOT, full_path)), exist_ok=True)
+        with open(os.path.join(ROOT, full_path), "w") as f:
+            json.dump(out, f, indent=1)
+        print(f"bench.py: full record in {full_path}", file=sys.stderr, flush=True)
+    except OSError as exc:
+        print(f"bench.py: could not write {full_path}: {exc}", file=sys.stderr, flush=True)
+        full_path = None
+    line = dumps(compact_line(out, full_path))
+    assert len(line) <= MAX_LINE_BYTES, len(line)
+    print(line, flush=True)
 
 
 if __name__ == "__main__":

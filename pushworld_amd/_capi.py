@@ -26,6 +26,7 @@ ORDER_PYTHON, ORDER_CPP = 0, 1
 PUZZLE_HEADER_BYTES = 320      # sizeof(PwPuzzleHeader), csrc/pw_format.h (asserted by pw_puzzleset_headers users)
 PUZZLE_HEADER_N_OFFSET = 6     # offsetof(PwPuzzleHeader, N): uint32 base, then uint8 W, H, N, G
 OBS_U8, OBS_F32 = 0, 1
+PLAN_MAX_ACTIONS = 65536  # PW_PLAN_MAX_ACTIONS of include/pushworld_amd.h: actions per pw_plan_states launch
 STEP_AUTORESET = 1
 
 
@@ -625,7 +626,10 @@ class Engine:
         check(lib.pw_next_state(self.handle, puzzle_index, xy_in, action, xy_out, info))
 
     def plan_states(self, puzzle_index: int, actions: bytes, start=None, dev_states=None):
-        """``pw_plan_states``: (states int8 [T + 1, N, 2], goal flags uint8 [T + 1]) as numpy arrays."""
+        """``pw_plan_states``: (states int8 [T + 1, N, 2], goal flags uint8 [T + 1]) as numpy arrays.
+
+        A plan of any length (the reference's ``is_valid_plan`` / ``render_plan`` accept any, puzzle.py:413-424, 471-506):
+        beyond ``PW_PLAN_MAX_ACTIONS`` actions per launch the plan continues from the last state of the previous chunk."""
         import numpy as np
 
         T = len(actions)
@@ -634,8 +638,21 @@ class Engine:
             raise ValueError("plan_states needs a puzzle set built from parsed puzzles")
         states = np.zeros((T + 1, n, 2), np.int8)
         goals = np.zeros((T + 1,), np.uint8)
-        check(lib.pw_plan_states(self.handle, puzzle_index, None if start is None else c_void_p(start.ctypes.data),
-                                 actions, T, c_void_p(states.ctypes.data), c_void_p(goals.ctypes.data), _ptr(dev_states)))
+        row = self.np * 2  # bytes per state of the device buffer (int8 [T + 1, np, 2])
+        dev_base = None if dev_states is None else dev_states.data_ptr()
+        t0 = 0
+        while True:
+            t1 = min(T, t0 + PLAN_MAX_ACTIONS)
+            if t0 == 0:
+                start_ptr = None if start is None else c_void_p(start.ctypes.data)
+            else:  # the chunk starts where the previous one ended (its first state is rewritten with the same values)
+                start_ptr = c_void_p(states[t0].ctypes.data)
+            check(lib.pw_plan_states(self.handle, puzzle_index, start_ptr, actions[t0:t1], t1 - t0,
+                                     c_void_p(states[t0:].ctypes.data), c_void_p(goals[t0:].ctypes.data),
+                                     None if dev_base is None else c_void_p(dev_base + t0 * row)))
+            if t1 >= T:
+                break
+            t0 = t1
         return states, goals
 
     # state buffers -------------------------------------------------------------------

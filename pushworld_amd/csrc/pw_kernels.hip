@@ -26,6 +26,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -163,9 +164,9 @@ struct PwEngine {
   hipStream_t lat_stream;
   void* lat_host;          // pinned host memory mapped into the device: results + completion word
   void* lat_dev;           // the device's address of lat_host
-  uint8_t* lat_actions;    // device copy of a plan's actions (PW_PLAN_MAX_ACTIONS bytes)
   size_t lat_bytes;
   uint32_t lat_seq;        // completion word of the last launch
+  std::mutex lat_mu;       // pw_next_state / pw_plan_states share lat_host and lat_seq: one call at a time per engine
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)

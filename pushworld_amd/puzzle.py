@@ -325,17 +325,6 @@ class PushWorldPuzzle:
         torch.cuda.current_stream(eng.device).synchronize()
         return view[0].numpy().copy()
 
-    def _render_device(self, state, border_width, pixels_per_cell, dtype) -> torch.Tensor:
-        eng = self._engine(pixels_per_cell, border_width, dtype)
-        b = self._state_bufs(eng)
-        self._upload(eng, state)
-        key = ("obs", pixels_per_cell, border_width, dtype)
-        if key not in self._bufs:
-            self._bufs[key] = eng.alloc_obs(1)
-        storage, view = self._bufs[key]
-        eng.render(b["pid"], b["pos"], storage)
-        return view[0]
-
     def render_plan(self, plan: Iterable[int], border_width: int = DEFAULT_BORDER_WIDTH,
                     pixels_per_cell: int = DEFAULT_PIXELS_PER_CELL) -> List[np.ndarray]:
         """puzzle.py:471-506: one ``pw_plan_states`` launch leaves every state of the plan in a device buffer, ONE batched

@@ -14,27 +14,60 @@ SMALL = ["--steps", "3", "--warmup", "1", "--windows", "2", "--envs-per-gpu", "2
 
 
 def run_bench(*argv, timeout=600, extra_env=None):
+    """Runs bench.py; returns (process, [full record]).  What bench.py PRINTS is the compact line (<= 4 KB): it is
+    checked here for every run -- one line, short enough for the driver's stdout tail, `roofline` / `cpu_baseline` at the top
+    level, the contract fields equal to the full record's -- and the tests then read the full record from the side file."""
+    import tempfile
+
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST"):
         env.pop(k, None)
     env.update(extra_env or {})
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
-                          timeout=timeout, env=env, cwd=ROOT)
-    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
-    return proc, [json.loads(l) for l in lines]
+    with tempfile.TemporaryDirectory() as tmp:
+        full_path = os.path.join(tmp, "full.json")
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, "--full-record", full_path],
+                              capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+        fulls = []
+        for l in lines:
+            assert len(l) < 4096, len(l)
+            c = json.loads(l)
+            with open(full_path) as f:
+                full = json.load(f)
+            for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"):
+                assert c[key] == full[key], key
+            assert c["config"]["workload"] == full["config"]["workload"] and c["full_record"] == full_path
+            r = c["roofline"]
+            assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+            assert r["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-3) and "traffic" in r and "avg_launch_ms" in r
+            if "cpu_baseline" in full:
+                cb = c["cpu_baseline"]
+                assert cb["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-3) and cb["kind"] == "port"
+                assert cb["cores"] >= 1 and cb["unit"] == "env-steps/s" and cb["sample"]
+            if "configs" in full:
+                assert set(c["configs"]) == set(full["configs"]) - {"C3_u8_ppc3"}
+            fulls.append(full)
+    proc.compact_lines = [json.loads(l) for l in lines]
+    return proc, fulls
 
 
 def test_self_spawned_two_ranks_sum_their_counters():
     """``python bench.py --gpus 2`` (no torchrun) starts two ranks itself.  With one device on the box both ranks
     share it and the counters go over gloo (RCCL refuses two ranks on one GPU); with two or more it is the real
-    one-rank-per-GPU RCCL path.  ONE JSON line, n_gpus == 2, counters summed, cpu_baseline kept for N > 1."""
+    one-rank-per-GPU RCCL path.  ONE JSON line, n_gpus == 2, counters summed; the cpu_baseline belongs to the N = 1 line."""
     import torch
 
     shared = [] if torch.cuda.device_count() >= 2 else ["--shared-device"]
     # an N = 1 run of the same workload first: it leaves the reference value of `scaling_efficiency`
-    proc1, lines1 = run_bench(*SMALL, "--no-cpu-baseline")
+    proc1, lines1 = run_bench(*SMALL, "--cpu-seconds", "0.5")
     assert proc1.returncode == 0 and len(lines1) == 1, proc1.stderr[-2000:]
     assert "scaling_efficiency" not in lines1[0] and len(lines1[0]["roofline"]["per_rank_frac"]) == 1
+    cb = lines1[0]["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["one_thread"]["cores"] == 1 and cb["cpu_model"]
+    assert cb["python_env"]["value"] > 0 and cb["python_env"]["processes"]["cores"] >= 1
+    assert proc1.compact_lines[0]["cpu_baseline"]["one_thread_value"] == pytest.approx(cb["one_thread"]["value"], rel=1e-3)
+    assert proc1.compact_lines[0]["config"]["ranks_in_probe_all_reduce"] is None
     proc, lines = run_bench("--gpus", "2", *shared, *SMALL, "--cpu-seconds", "1")
     assert proc.returncode == 0, proc.stderr[-2000:]
     assert len(lines) == 1, proc.stdout[-2000:]
@@ -66,9 +99,9 @@ def test_self_spawned_two_ranks_sum_their_counters():
     # both statistics: per window the slowest rank (the headline) and every rank's own median rate, summed
     assert d["timing"]["sum_of_per_rank_median_rates"] >= d["value"] * 0.999
     assert se["sum_of_per_rank_rates_over_n_x_n1"] >= se["value"] * 0.999
-    cb = d["cpu_baseline"]
-    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["one_thread"]["cores"] == 1 and cb["cpu_model"]
-    assert cb["python_env"]["value"] > 0 and cb["python_env"]["processes"]["cores"] >= 1
+    assert "cpu_baseline" not in d  # (rank 0 at N = 1 only)
+    if not shared:
+        assert d["config"]["ranks_in_probe_all_reduce"] == 2
 
 
 def test_rccl_branch_runs_with_one_rank():
@@ -87,6 +120,7 @@ def test_rccl_branch_runs_with_one_rank():
     assert len(lines) == 1
     d = lines[0]
     assert d["n_gpus"] == 1 and "counters over nccl" in d["config"]["parallelism"]
+    assert d["config"]["ranks_in_probe_all_reduce"] == 1 and proc.compact_lines[0]["config"]["ranks_in_probe_all_reduce"] == 1
     assert d["config"]["global_batch"] == 2048 and abs(d["value"] - 2048 * 3 / (d["ms_per_step"] * 3 / 1000.0)) < 1e-6 * d["value"]
     assert len(d["roofline"]["per_rank_frac"]) == 1 and len(d["timing"]["per_rank_median_ms_per_step"]) == 1
 

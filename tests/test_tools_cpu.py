@@ -75,3 +75,42 @@ def test_pmc_records_are_refused_for_another_kernel_source(tmp_path, monkeypatch
     assert t is None and "stale" in why
     # the state-only bytes model of SURVEY 8d
     assert [cs.state_bytes(n) for n in (4, 16, 32)] == [38, 86, 150]
+
+
+def test_compact_bench_line_fits_the_driver_tail():
+    """what bench.py prints is at most 4 KB whatever the full record holds -- here round 4's own 22 KB record
+    (which the driver could not parse), the same with eight ranks' per-rank rows and with every optional object bloated."""
+    from tools.bench_line import MAX_LINE_BYTES, compact_line, dumps
+
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    line = dumps(compact_line(full, "gpurun_out/bench_full.json"))
+    assert len(line) <= MAX_LINE_BYTES < 4096
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data"):
+        assert d[key] == full[key], key  # the contract's fields keep every digit
+    r = d["roofline"]
+    assert r["kernel"] == "pw_render_page_kernel" and r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - full["roofline"]["frac"]) < 1e-4 and abs(r["traffic_ratio"] - 1.0045) < 1e-3
+    assert r["avg_launch_ms"] > 0 and r["algorithmic_bytes_per_launch"] == full["roofline"]["algorithmic_bytes_per_launch"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 128 and cb["cpu_model"] and cb["one_thread_value"] > 0 and cb["python_env_value"] > 0
+    assert d["config"]["workload"] == full["config"]["workload"] and d["config"]["envs_per_gpu"] == 65536
+    assert set(d["configs"]) == set(full["configs"]) - {"C3_u8_ppc3"}
+    for name, e in d["configs"].items():
+        assert e["value"] > 0 and e["unit"], name
+    assert d["configs"]["C4_state"]["rollout64"]["value"] > d["configs"]["C4_state"]["value"]
+    # eight ranks and bloated optional parts: still inside the limit, the three contract objects still there
+    big = json.loads(json.dumps(full))
+    big["n_gpus"] = 8
+    big["timing"]["per_rank_median_ms_per_step"] = [0.5696312345] * 8
+    big["config"]["workload"] = big["config"]["workload"] + " x" * 300
+    for e in big["configs"].values():
+        e["kernel"] = "pw_some_kernel_with_a_very_long_name<template, arguments, of, all, kinds>(Args)"
+        e["hbm_frac"], e["traffic_ratio"] = 0.123456789, 1.23456789
+    line8 = dumps(compact_line(big, "gpurun_out/bench_full_n8.json"))
+    assert len(line8) <= MAX_LINE_BYTES
+    d8 = json.loads(line8)
+    assert d8["value"] == full["value"] and "roofline" in d8 and "cpu_baseline" in d8 and d8["config"]["envs_per_gpu"] == 65536

@@ -33,6 +33,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
+# CPU baselines of the non-headline configurations: short bounded samples (the whole default bench.py run has to fit a minute;
+# the headline's own cpu_baseline takes three samples of --cpu-seconds each)
+CPU_SECONDS, CPU_SAMPLES = 0.6, 2
 CSRC = os.path.join(ROOT, "pushworld_amd", "csrc")
 
 
@@ -89,15 +92,22 @@ def launch_ms(eng, fn, launches):
 
 
 def entry(value, unit, workload, kernel, bytes_per_unit, units_per_launch, ms, config_key=None, **extra):
+    """``frac`` is the MODEL fraction: SURVEY 8d's algorithmic bytes of the launch / its average duration / the 8 TB/s peak.
+    ``hbm_frac`` is the MEASURED one: the recorded PMC traffic of the same launch / the same duration / the peak;
+    ``traffic_ratio`` = traffic / algorithmic bytes (1.0 = the launch moves exactly what the model charges; VERDICT r4 #2)."""
     avg = float(ms.mean())
     achieved = bytes_per_unit * units_per_launch / (avg * 1e-3) / 1e9
     out = {"value": value, "unit": unit, "workload": workload, "kernel": kernel,
            "algorithmic_bytes_per_unit": bytes_per_unit, "units_per_launch": int(units_per_launch),
            "avg_launch_ms": avg, "median_launch_ms": float(np.median(ms)), "min_launch_ms": float(ms.min()),
            "launches_timed": int(len(ms)), "achieved_gbs": achieved, "peak_gbs": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
+           "frac_is": "model: algorithmic bytes per launch / average launch time / peak",
            "timer": "HIP events recorded by the library around the launch, on the launch stream"}
     if config_key:
         out["traffic"], out["traffic_source"] = pmc_traffic(config_key, units_per_launch)
+        if out["traffic"]:
+            out["hbm_frac"] = out["traffic"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["traffic_ratio"] = out["traffic"] / (bytes_per_unit * units_per_launch)
     out.update(extra)
     return out
 
@@ -105,6 +115,12 @@ def entry(value, unit, workload, kernel, bytes_per_unit, units_per_launch, ms, c
 def state_bytes(npad):
     # positions read + written, action, puzzle id, step counter r/w, flags, dgoals, f64 reward
     return 4 * npad + 22
+
+
+def rollout_bytes(npad, T):
+    """Algorithmic bytes per ENV-STEP of a T-step pw_rollout launch: the state is read once and written once per launch
+    (positions r/w, puzzle id, step counter r/w, the last step's reward / delta / flags), one action byte per step."""
+    return (4 * npad + 21 + T) / T
 
 
 def actions_for(T, B, dev, seed):
@@ -184,9 +200,9 @@ def run_c1(cpu=True):
             from tools.cpu_baselines import python_env_rate, port_rollout_rate
 
             w, h = pz.dimensions
-            py_r = python_env_rate([text], 100, True, h, w, 20, 2, seconds=1.5)
-            py_s = python_env_rate([text], 100, False, h, w, 20, 2, seconds=1.0)
-            cp = port_rollout_rate([text], np.zeros(64, np.int64), 100, 0, h, w, 20, 2, seconds=0.5, sample_envs=64, with_one_thread=False)
+            py_r = python_env_rate([text], 100, True, h, w, 20, 2, seconds=1.0)
+            py_s = python_env_rate([text], 100, False, h, w, 20, 2, seconds=0.6)
+            cp = port_rollout_rate([text], np.zeros(64, np.int64), 100, 0, h, w, 20, 2, seconds=0.4, samples=CPU_SAMPLES, sample_envs=64, with_one_thread=False)
             out["cpu_baseline"] = {"value": py_r["value"], "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
                                    "sample": py_r["sample"] + " [uint8 observation ppc 20]",
                                    "state_only": {"value": py_s["value"], "sample": py_s["sample"]},
@@ -221,8 +237,9 @@ def run_c2(cpu=True):
                 note="64 wavefronts on the whole chip: launch / latency bound by construction (SURVEY 8d)")
     dtr = wall(lambda: vec.rollout(acts), 300, 5)
     msr = launch_ms(vec.engine, lambda: vec.rollout(acts), 100)
-    out["rollout_64_steps_per_launch"] = entry(B * T / dtr, "env-steps/s", "the same batch, pw_rollout: 64 steps per launch", kern, sb,
-                                               B * T, msr, "C2_rollout")
+    out["rollout_64_steps_per_launch"] = entry(B * T / dtr, "env-steps/s", "the same batch, pw_rollout: 64 steps per launch (state in registers "
+                                               "between the steps: per launch the state once in, once out + 64 action bytes)", kern,
+                                               rollout_bytes(vec.engine.np, T), B * T, msr, "C2_rollout")
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for k in range(T):
@@ -234,7 +251,7 @@ def run_c2(cpu=True):
     if cpu:
         from tools.cpu_baselines import port_rollout_rate
 
-        out["cpu_baseline"] = port_rollout_rate([text], np.zeros(B, np.int64), 100, 0, 7, 7, 3, 1, seconds=1.0, with_one_thread=False)
+        out["cpu_baseline"] = port_rollout_rate([text], np.zeros(B, np.int64), 100, 0, 7, 7, 3, 1, seconds=CPU_SECONDS, samples=CPU_SAMPLES, with_one_thread=False)
     return out
 
 
@@ -279,7 +296,7 @@ def run_c3(obs, ppc, bw, B, key, steps, cpu=True, cpu_envs=4096):
     if cpu:
         from tools.cpu_baselines import port_rollout_rate
 
-        out["cpu_baseline"] = port_rollout_rate(texts, ids, 200, "f32" if obs == "float32" else "u8", 51, 42, ppc, bw, seconds=1.5,
+        out["cpu_baseline"] = port_rollout_rate(texts, ids, 200, "f32" if obs == "float32" else "u8", 51, 42, ppc, bw, seconds=CPU_SECONDS, samples=CPU_SAMPLES,
                                                 sample_envs=cpu_envs, with_one_thread=False)
     return out
 
@@ -313,8 +330,9 @@ def run_c4(obs, key, cpu=True):
                     note="latency / issue bound, far below the HBM roofline by construction (SURVEY 8d)")
         dtr = wall(lambda: vec.rollout(acts), 40, 3)
         msr = launch_ms(eng, lambda: vec.rollout(acts), 20)
-        out["rollout_64_steps_per_launch"] = entry(B * T / dtr, "env-steps/s", "the same shard, pw_rollout: 64 steps per launch",
-                                                   "pw_step_group_mixed_kernel", sb, B * T, msr, "C4_rollout")
+        out["rollout_64_steps_per_launch"] = entry(B * T / dtr, "env-steps/s", "the same shard, pw_rollout: 64 steps per launch (state in "
+                                                   "registers between the steps: per launch the state once in, once out + 64 action bytes)",
+                                                   "pw_step_group_mixed_kernel", rollout_bytes(eng.np, T), B * T, msr, "C4_rollout")
     else:
         for _ in range(3):
             one()
@@ -333,7 +351,7 @@ def run_c4(obs, key, cpu=True):
     if cpu:
         from tools.cpu_baselines import port_rollout_rate
 
-        out["cpu_baseline"] = port_rollout_rate(texts, ids, 200, "u8" if obs else 0, 54, 47, 3, 1, seconds=1.5, with_one_thread=False)
+        out["cpu_baseline"] = port_rollout_rate(texts, ids, 200, "u8" if obs else 0, 54, 47, 3, 1, seconds=CPU_SECONDS, samples=CPU_SAMPLES, with_one_thread=False)
     return out
 
 
@@ -404,7 +422,7 @@ def run_c5(key, rel, cpu=True):
         from tools.cpu_baselines import port_expand_rate
 
         with open(os.path.join(BENCHMARK_PUZZLES_PATH, rel)) as f:
-            out["cpu_baseline"] = port_expand_rate(f.read(), st_host, seconds=0.7)
+            out["cpu_baseline"] = port_expand_rate(f.read(), st_host, seconds=0.4, samples=CPU_SAMPLES)
     return out
 
 
