@@ -286,6 +286,11 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_EXPAND_WG_WAVES 29 /* pw_expand4_v2_kernel with tables so large that one workgroup fits a CU: 4 or 8 wavefronts per workgroup (0 = automatic: 8
                                     where its LDS has staging room for them) */
 #define PW_OPT_SEARCH_BATCH_GROUPS_PER_CU 28 /* pw_search_batch: persistent workgroups per CU (0 = automatic) */
+#define PW_OPT_STEP_QUAD16 31        /* puzzles whose grid fits 16 x 16 cells with at most 8 movables of at most 16 x 8 cells (every Level-0
+                                      puzzle): workgroups whose 32 environments all play such puzzles keep every board in registers, four
+                                      lanes per environment, the puzzle in ONE 576-byte record (no table, no header walk): 0 automatic
+                                      (sets with overlap tables for every puzzle: the fallback for states outside the grid), 2 never */
+#define PW_OPT_STEP_QUAD16_PUZZLES 32 /* read-only: puzzles of the set with such a record */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order

@@ -128,6 +128,10 @@ struct PwEngine {
   uint64_t* d_boards;      // [set size][2] whole-grid wall / wall + agent-wall boards when EVERY puzzle fits 8 x 8 cells and has at
                            // most 8 movables (pw_step_board_kernel), else NULL
   int step_boards;         // PW_OPT_STEP_BOARDS: 0 automatic (state-only launches of such sets), 2 never
+  uint8_t* d_qdesc;        // [set size] PwQuadDesc records (PW_QD_BYTES each): whole-grid 16 x 16 boards, four lanes per environment
+                           // (step_quad16_body); a record with N = 0: the puzzle does not fit
+  int quad_puzzles;        // puzzles of the set that fit
+  int step_quad16;         // PW_OPT_STEP_QUAD16: 0 automatic (workgroups whose 32 environments all fit), 2 never
   PwPushDir* d_push_dir;   // [set size], or NULL (sets of more than 64 puzzles carry no push tables)
   std::vector<uint8_t> push_has;  // [set size] host copy: puzzle p has push tables
   std::vector<PwPushDir> push_host;  // [set size] host copy of d_push_dir

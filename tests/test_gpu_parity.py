@@ -51,6 +51,8 @@ def _step_options(kernel):
     steps; pools with more than 16 movables per puzzle: two per lane), "group-lds" (row tables staged in LDS, the
     default of multi-step rollouts), "group-wide" (32-lane groups), "lane", "wave"; "group-tables" / "group-notables":
     overlap tables (PW_OPT_STEP_TABLES) for every puzzle / for none (default: for puzzles with movables beyond 8 x 8)."""
+    if kernel == "group-noquad":  # the defaults without the 16 x 16 whole-grid boards (the lane groups for every workgroup)
+        return {"step_kernel": "group", "step_lds_tables": 2, "step_boards": "never", "step_quad16": "never"}
     if kernel == "group-narrow":  # N_pad 16 pools: 8 lanes per environment, two movables per lane
         return {"step_boards": "never", "step_kernel": "group", "step_lds_tables": 2, "step_narrow_groups": 1}
     if kernel == "group-unmixed":  # N_pad 8 / 16 pools: ONE choice of lanes for the whole set (default: per workgroup of 32 environments)
@@ -91,6 +93,7 @@ def _step_options(kernel):
                                           ("bench", "lane-notables"), ("tests", "lane-notables"),
                                           ("bench", "big-batch"), ("l0", "big-batch"),
                                           ("tiny", "boards"), ("tiny", "group"),
+                                          ("l0", "group-noquad"), ("tiny", "group-noquad"), ("level1", "group-noquad"), ("tests", "group-noquad"),
                                           ("bench", "wave"), ("tests", "wave")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
@@ -153,7 +156,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
         assert (trunc_hist[:L, b] == want_trunc).all(), (k, name)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-16lanes", "group-tables", "group-notables", "group-bigtables",
+@pytest.mark.parametrize("kernel", ["group", "group-noquad", "group-lds", "group-wide", "group-16lanes", "group-tables", "group-notables", "group-bigtables",
                                     "lane", "lane-notables", "wave", "boards"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
@@ -495,7 +498,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
                 assert (img[b] == o.observation(st, fh, fw, 3, 1, dtype="u8")).all(), (k, seq[0], t)
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-lds", "group-wide", "group-16lanes", "group-notables", "group-bigtables", "group-level1",
+@pytest.mark.parametrize("kernel", ["group", "group-noquad", "group-lds", "group-wide", "group-16lanes", "group-notables", "group-bigtables", "group-level1",
                                     "group-narrow", "lane", "lane-notables", "big-batch", "boards"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):

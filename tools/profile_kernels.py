@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--states", type=int, default=4_000_000)
     ap.add_argument("--puzzle", default="level4/Four Pistons.pwp")
     ap.add_argument("--lds-tables", default="auto", choices=("auto", "never"))
+    ap.add_argument("--lanes", action="store_true", help="c4_step: one lane per environment whatever the batch (PW_OPT_STEP_LANE_BATCH 1)")
     ap.add_argument("--rollouts", type=int, default=4, help="c4_step / c2_step: 64-step pw_rollout launches after the single steps")
     args = ap.parse_args()
     from tools import config_suite as cs
@@ -38,6 +39,8 @@ def main():
 
         ns = argparse.Namespace(envs_per_gpu=65536, obs="none", config="c4", max_steps=200, bw=1, ppc=3, tune_allocations=None)
         vec = bench.build_workload(ns, 0, 8, 0)["vec"]
+        if args.lanes:
+            vec.engine.set_option("step_lane_batch", 1)
         vec.reset()
         acts = cs.actions_for(64, 65536, vec.device, 100)
         torch.cuda.synchronize()
