@@ -46,6 +46,9 @@ def lib():
         l.or_rollout_trace.restype = None
         l.or_rollout_trace.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_int, c_int, POINTER(c_uint8), c_int, c_int,
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        l.or_rollout_digest.restype = None
+        l.or_rollout_digest.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_int, c_int, POINTER(c_uint8), c_int, c_int,
+                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         l.or_observe_batch.restype = None
         l.or_observe_batch.argtypes = [POINTER(c_void_p), POINTER(c_int32), c_void_p, c_int, POINTER(c_int32), c_int,
                                        c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -159,6 +162,30 @@ def rollout_trace(puzzles, puzzle_ids, actions, max_steps, autoreset, np_pad):
                            int(-1 if max_steps is None else max_steps), int(bool(autoreset)), int(np_pad),
                            pos.ctypes.data, reward.ctypes.data, term.ctypes.data, trunc.ctypes.data, steps.ctypes.data)
     return pos, reward, term, trunc, steps
+
+
+def rollout_digest(puzzles, puzzle_ids, actions, max_steps, autoreset, np_pad, weights):
+    """``rollout_trace`` for long runs of big batches: per step and environment a 64-bit linear digest of the position row
+    (``sum_k row[k] * weights[k]`` mod 2^64, ``weights`` int64 [np_pad * 2]) instead of the row; the rows themselves only after
+    the last step.  Returns ``digest int64 [T, B], reward f64 [T, B], terminated u8 [T, B], truncated u8 [T, B], steps i32
+    [T, B], pos_last int8 [B, np_pad, 2]``."""
+    handles = (c_void_p * len(puzzles))(*[p.handle for p in puzzles])
+    pid = np.ascontiguousarray(np.asarray(puzzle_ids, dtype=np.int32))
+    acts = np.ascontiguousarray(np.asarray(actions, dtype=np.uint8))
+    w = np.ascontiguousarray(np.asarray(weights, dtype=np.int64))
+    assert w.shape == (np_pad * 2,)
+    T, B = acts.shape
+    digest = np.zeros((T, B), np.int64)
+    reward = np.zeros((T, B), np.float64)
+    term = np.zeros((T, B), np.uint8)
+    trunc = np.zeros((T, B), np.uint8)
+    steps = np.zeros((T, B), np.int32)
+    pos_last = np.zeros((B, np_pad, 2), np.int8)
+    lib().or_rollout_digest(handles, pid.ctypes.data_as(POINTER(c_int32)), B, T, acts.ctypes.data_as(POINTER(c_uint8)),
+                            int(-1 if max_steps is None else max_steps), int(bool(autoreset)), int(np_pad), w.ctypes.data,
+                            digest.ctypes.data, reward.ctypes.data, term.ctypes.data, trunc.ctypes.data, steps.ctypes.data,
+                            pos_last.ctypes.data)
+    return digest, reward, term, trunc, steps, pos_last
 
 
 def observe_batch(puzzles, puzzle_ids, pos, sel, pad_h, pad_w, ppc, bw, dtype="u8"):

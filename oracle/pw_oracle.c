@@ -467,6 +467,53 @@ void or_rollout_trace(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T
   }
 }
 
+/* or_rollout_trace for long runs of big batches: instead of every position row, a 64-bit LINEAR digest of it per step and
+ * environment -- digest[t][b] = sum_k row[k] * weights[k] (mod 2^64) over the np * 2 int8 values of the row -- which the test
+ * forms from the engine's positions with the same weights; the full rows only after the last step (pos_last int8 [B][np][2]). */
+void or_rollout_digest(OrPuzzle* const* puzzles, const int32_t* pid, int B, int T, const uint8_t* actions, int max_steps,
+                       int autoreset, int np, const int64_t* weights, int64_t* digest, double* reward, uint8_t* term,
+                       uint8_t* trunc, int32_t* steps, int8_t* pos_last) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int b = 0; b < B; b++) {
+    const OrPuzzle* p = puzzles[pid[b]];
+    int state[2 * MAXN];
+    for (int j = 0; j < p->N; j++) {
+      state[2 * j] = p->init[j][0];
+      state[2 * j + 1] = p->init[j][1];
+    }
+    int n = 0, te = 0, tr = 0;
+    for (int t = 0; t < T; t++) {
+      double r = 0.0;
+      if (autoreset && (te | tr)) {
+        for (int j = 0; j < p->N; j++) {
+          state[2 * j] = p->init[j][0];
+          state[2 * j + 1] = p->init[j][1];
+        }
+        n = 0;
+        te = 0;
+        tr = 0;
+      } else {
+        te = or_env_step(p, state, actions[(size_t)t * B + b] & 3, &r);
+        n++;
+        tr = (max_steps >= 0 && n >= max_steps) ? 1 : 0;
+      }
+      const size_t o = (size_t)t * B + b;
+      uint64_t d = 0;
+      for (int k = 0; k < 2 * p->N && k < 2 * np; k++) d += (uint64_t)(int64_t)(int8_t)state[k] * (uint64_t)weights[k];
+      digest[o] = (int64_t)d;
+      reward[o] = r;
+      term[o] = (uint8_t)te;
+      trunc[o] = (uint8_t)tr;
+      steps[o] = n;
+    }
+    int8_t* row = pos_last + (size_t)b * np * 2;
+    for (int j = 0; j < np; j++) {
+      row[2 * j] = j < p->N ? (int8_t)state[2 * j] : 0;
+      row[2 * j + 1] = j < p->N ? (int8_t)state[2 * j + 1] : 0;
+    }
+  }
+}
+
 /* Padded observations (uint8, or float32 when f32 != 0) of the K environments sel[0..K-1] of a batch whose
  * positions are pos int8 [B][np][2]; out is [K][pad_h * ppc][pad_w * ppc][3]. */
 void or_observe_batch(OrPuzzle* const* puzzles, const int32_t* pid, const int8_t* pos, int np, const int32_t* sel, int K,

@@ -35,7 +35,7 @@ def _pool(kind):
         assert len(five) >= 10
         return l0[:120] + five
     texts = list(l0[:150])
-    for lv in (1, 4):  # (Level 4 has the puzzles with more than 16 movables: N_pad 32)
+    for lv in (1, 2):  # (Level 2 has the one puzzle with more than 16 movables, `Clean Sweep`: N_pad 32)
         for p in bd.level_paths(lv)[:30]:
             with open(p) as f:
                 texts.append(f.read())
