@@ -290,6 +290,13 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       puzzle): workgroups whose 32 environments all play such puzzles keep every board in registers, four
                                       lanes per environment, the puzzle in ONE 576-byte record (no table, no header walk): 0 automatic
                                       (sets with overlap tables for every puzzle: the fallback for states outside the grid), 2 never */
+#define PW_OPT_SEARCH_KEYS 33        /* closed set of pw_search_create (read at creation): 0 (default) fingerprint + index entries; 1 where a
+                                      state packs into 63 bits (bits per coordinate x movables) and the start state overlaps no wall, a
+                                      published entry is the packed state itself (a visited state is recognised without reading the
+                                      stored state).  Same results and, measured, the same HBM bytes; kept for the A/B */
+#define PW_OPT_EXPAND_PAIR_DIMS 34   /* pw_expand4 with the tables in LDS: 0 automatic -- byte pair tables sized PER PAIR (h_i + h_j + 2 rows of
+                                      w_i + w_j + 2 bytes) where the set-wide 2 max_h + 2 by 2 max_w + 2 tables exceed 16 KB, 7 .. 16
+                                      movables --, 2 never (set-wide tables, or the lane kernel where those do not fit LDS) */
 #define PW_OPT_STEP_QUAD16_PUZZLES 32 /* read-only: puzzles of the set with such a record */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);

@@ -192,6 +192,8 @@ OPTIONS = {
     "search_batch_groups_per_cu": 28,  # pw_search_batch: persistent workgroups per CU (0 = automatic)
     "expand_groups_per_cu": 27,  # ... persistent workgroups per CU (0 = automatic)
     "step_quad16": 31,         # 16 x 16 whole-grid boards, four lanes per environment: 0 / "auto", 2 / "never"
+    "search_keys": 33,         # closed set of the searches created afterwards: 0 / "fingerprint" (default), 1 / "exact" 63-bit keys where they fit
+    "expand_pair_dims": 34,    # pw_expand4 (tables in LDS): 0 / "auto" pair tables sized per pair where the uniform ones exceed 16 KB, 2 / "never"
     "step_quad16_puzzles": 32, # read-only: puzzles of the set that fit
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
 }
@@ -202,6 +204,8 @@ _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds":
 # names that mean different numbers for different options ("never" is a batch threshold for step_lane_batch)
 _OPTION_VALUES_BY_KEY = {"step_boards": {"auto": 0, "never": 2},
                          "step_quad16": {"auto": 0, "never": 2},
+                         "search_keys": {"fingerprint": 0, "exact": 1},
+                         "expand_pair_dims": {"auto": 0, "never": 2},
                          "step_narrow_groups": {"auto": 0, "always": 1, "never": 2},
                          "expand_lds_tables": {"auto": 0, "never": 2},
                          "step_mixed_groups": {"auto": 0, "never": 2},

@@ -75,6 +75,12 @@ struct PwPushDir {
   uint16_t reserved;
   uint32_t pairb_bytes; // N * N * (R2 + 1) * CWB rounded up to 16
   uint32_t reserved2;
+  // the same byte tables sized PER PAIR (round 5): table (i, j) has h_i + h_j + 2 rows of w_i + w_j + 2 bytes (the last row and
+  // column are the zero guards) instead of the set-wide 2 max_h + 2 by 2 max_w + 2 -- one big movable no longer inflates the
+  // tables of every pair (`Pinhole Lock`, N = 14: 98.8 -> 10.1 KB; 44 benchmark puzzles beyond 16 KB become 1).  The block starts
+  // with N * N descriptors: byte offset of the table inside the block | columns << 16 | guard row index << 24.
+  uint32_t pairp_off;   // 8-byte units from d_ovl; 0 = none (uniform tables are small enough, or the block exceeds 64 KB)
+  uint32_t pairp_bytes; // descriptors + tables, rounded up to 16
 };
 
 // An observation buffer owned by the library (pw_obs_alloc): one reserved address range backed by physical chunks
@@ -113,6 +119,7 @@ struct PwEngine {
   bool force_lds_render;   // PW_OPT_RENDER_KERNEL = 1: per-environment LDS kernel even where the page kernel applies
   int64_t page_slice_envs; // PW_OPT_PAGE_SLICE_ENVS: environments per page-kernel launch (0 = what 2^31 chunks allow)
   int64_t search_chunk;    // PW_OPT_SEARCH_CHUNK: parents per pw_search_expand pass (0 = 2^20)
+  int search_keys;         // PW_OPT_SEARCH_KEYS: closed set of pw_search_*: 0 fingerprinted entries, 1 exact 63-bit keys where the state packs
   int step_mixed;          // PW_OPT_STEP_MIXED_GROUPS: lanes per environment chosen per workgroup on N_pad 8 / 16 sets (0 auto, 2 never)
   int step_wide_groups;    // PW_OPT_STEP_WIDE_GROUPS: 32 lanes per environment for N_pad 32 instead of two movables per lane
   int64_t step_lane_batch; // PW_OPT_STEP_LANE_BATCH: state-only launches from this batch size on run one lane per environment
@@ -137,6 +144,7 @@ struct PwEngine {
   std::vector<PwPushDir> push_host;  // [set size] host copy of d_push_dir
   int expand_lds_tables;   // PW_OPT_EXPAND_LDS_TABLES: 0 automatic (pw_expand4_v2_kernel where the tables fit LDS), 2 never
   int expand_tile_order;   // PW_OPT_EXPAND_TILE_ORDER: pw_expand4_v2_kernel: 0 tiles interleaved, 1 a contiguous eighth per XCD
+  int expand_pair_dims;    // PW_OPT_EXPAND_PAIR_DIMS: pw_expand4_v2_kernel with pair tables sized per pair: 0 automatic, 2 never
   int expand_prefetch;     // PW_OPT_EXPAND_PREFETCH: ... loads the next tile's rows while it computes this one
   int expand_wg_waves;  // PW_OPT_EXPAND_WG_WAVES: cap on the wavefronts of a lone workgroup per CU (0 = automatic)
   int search_batch_groups_per_cu;  // PW_OPT_SEARCH_BATCH_GROUPS_PER_CU (0 = automatic)

@@ -360,3 +360,53 @@ def test_million_state_frontier_against_the_oracle(golden, key):
     assert (goal.cpu().numpy() == want_goal).all()
     # the layers the search itself produced are closed under expansion up to the last complete layer
     assert want_moved.any() and got_succ.shape == (F, 4, pz.num_movables)
+
+
+def test_pair_tables_sized_per_pair_against_the_oracle():
+    """pw_expand4_v2_kernel<., ., ., true>: byte pair tables sized per pair (PwPushDir::pairp_off), chosen where the set-wide
+    tables exceed 16 KB -- 44 benchmark puzzles with 7 .. 16 movables, among them every one of round 4's slow tail but `Clean
+    Sweep`.  For every such puzzle a breadth-first frontier of >= 140 000 states (C++ object order): successors, moved masks and
+    goal flags of every state equal the C oracle's, and the kernel it replaces (PW_OPT_EXPAND_PAIR_DIMS never: set-wide tables, or
+    the lane kernel where those do not fit LDS) agrees word for word."""
+    from oracle import c_oracle
+    from pushworld_amd import benchmark_data as bd
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.search import BreadthFirstSearch
+
+    checked = 0
+    for lv in (1, 2, 3, 4):
+        for path in bd.level_paths(lv):
+            with open(path) as f:
+                text = f.read()
+            oz = c_oracle.COraclePuzzle(text, order="cpp")
+            n = oz.num_movables
+            dims = [(1 + max(c[0] for c in s) - min(c[0] for c in s), 1 + max(c[1] for c in s) - min(c[1] for c in s)) for s in oz.py.shapes]
+            uniform = n * n * (2 * max(d[1] for d in dims) + 2) * (2 * max(d[0] for d in dims) + 2)
+            if not (7 <= n <= 16 and uniform > 16384):
+                continue
+            pz = PushWorldPuzzle(text=text, order="cpp")
+            bfs_gpu = BreadthFirstSearch(pz, max_states=400_000)
+            bfs_gpu.begin()
+            try:
+                while bfs_gpu.total_states < 140_000 and not bfs_gpu.exhausted:
+                    bfs_gpu.expand()
+            except ValueError:  # the store filled up inside a layer: what is in it is enough
+                pass
+            F = min(bfs_gpu.total_states, 200_000)
+            xy = bfs_gpu.states(0, F)
+            bfs_gpu.close()
+            if F < 131_072:  # (a small state space: repeated up to the size from which pw_expand4 runs one lane per state)
+                xy = np.tile(xy, (-(-140_000 // F), 1, 1))[:140_000]
+                F = len(xy)
+            states = np.ascontiguousarray((xy[:, :, 0].astype(np.int64) * 10000 + xy[:, :, 1]).astype(np.int32))
+            eng = pz._engine()
+            eng.set_option("expand_pair_dims", "auto")
+            succ, moved, goal = (t.cpu().numpy() for t in pz.expand4(states))
+            eng.set_option("expand_pair_dims", "never")
+            succ0, moved0, goal0 = (t.cpu().numpy() for t in pz.expand4(states))
+            eng.set_option("expand_pair_dims", "auto")
+            assert (succ == succ0).all() and (moved == moved0).all() and (goal == goal0).all(), path
+            want_succ, want_moved, want_goal = c_oracle.expand4_batch(oz, states)
+            assert (succ == want_succ).all() and (moved.astype(np.uint32) == want_moved).all() and (goal == want_goal).all(), path
+            checked += 1
+    assert checked >= 40

@@ -40,7 +40,7 @@ CASES = ["pytest:trivial.pwp", "pytest:trivial_obstacle.pwp", "pytest:trivial_to
          "l0:level0/all/train/level_0_all_train_3.pwp", "rand:3", "rand:17", "rand:42"]
 
 
-@pytest.mark.parametrize("chunk", [None, "7", "lanes", "mixed"])
+@pytest.mark.parametrize("chunk", [None, "7", "lanes", "mixed", "keys", "keys7", "keyslanes"])
 def test_bfs_numbering_equals_sequential_search(golden, chunk, monkeypatch):
     """Whole reachable space (capped at 60 000 states): every state, parent, action, layer boundary
     and the first goal index equal the host FIFO search; chunk=7 forces many passes per layer.  "lanes": the
@@ -50,6 +50,11 @@ def test_bfs_numbering_equals_sequential_search(golden, chunk, monkeypatch):
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
 
+    # "keys": published entries of the closed set are the exact packed states wherever a state fits 63 bits (PW_OPT_SEARCH_KEYS
+    # exact: every puzzle of CASES but the widest); the default is fingerprint + index entries for every puzzle
+    keys = bool(chunk) and chunk.startswith("keys")
+    if keys:
+        chunk = chunk[4:] or None
     lanes = chunk in ("lanes", "mixed")
     mixed = chunk == "mixed"
     chunk = None if lanes else chunk
@@ -65,6 +70,7 @@ def test_bfs_numbering_equals_sequential_search(golden, chunk, monkeypatch):
         if len(want_states) > cap:
             continue  # space larger than the cap: covered by the truncated test below
         pz = PushWorldPuzzle(text=text)
+        pz._engine().set_option("search_keys", "exact" if keys else "fingerprint")
         bfs = BreadthFirstSearch(pz, max_states=cap + 8, chunk=chunk_arg)
         bfs.begin()
         layer = 0
@@ -155,8 +161,10 @@ def test_bfs_store_overflow_and_errors(golden):
     bfs.close()
 
 
-@pytest.mark.parametrize("key,cap", [("bench:level1/2 Obstacle.pwp", 150000), ("bench:level2/Clean Sweep.pwp", 40000)])
-def test_bfs_large_layer_matches_host_prefix(golden, key, cap):
+@pytest.mark.parametrize("keys", ["fingerprint", "exact"])
+@pytest.mark.parametrize("key,cap", [("bench:level1/2 Obstacle.pwp", 150000), ("bench:level2/Clean Sweep.pwp", 40000),
+                                     ("bench:level2/Pull Dont Push.pwp", 300000)])
+def test_bfs_large_layer_matches_host_prefix(golden, key, cap, keys):
     """'2 Obstacle' explored to 150 000 states with the default pass size: the first 150 000 states of
     the sequential search, in the same order (exercises multi-block scans and hash-table growth);
     'Clean Sweep' has 19 movables (32-lane groups, 10 words per state)."""
@@ -167,6 +175,7 @@ def test_bfs_large_layer_matches_host_prefix(golden, key, cap):
     text = golden.text(key)
     oz = c_oracle.COraclePuzzle(text)
     pz = PushWorldPuzzle(text=text)
+    pz._engine().set_option("search_keys", keys)  # exact 63-bit keys (`2 Obstacle`, `Pull Dont Push`; not the 19 movables of `Clean Sweep`)
     bfs = BreadthFirstSearch(pz, max_states=cap)
     bfs.begin()
     try:

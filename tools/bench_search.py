@@ -43,6 +43,10 @@ def main():
     ap.add_argument("--max-states", type=int, default=40_000_000)
     ap.add_argument("--groups", action="store_true", help="lane groups for every pass (PW_OPT_STEP_LANE_BATCH never) instead "
                     "of one lane per parent from 131 072 parents on")
+    ap.add_argument("--keys", default="fingerprint", choices=("fingerprint", "exact"), help="closed set: fingerprint + index entries / exact 63-bit keys where they fit")
+    ap.add_argument("--only", default=None, help="substring of the puzzle path")
+    ap.add_argument("--stop-at", type=int, default=0, help="stop once this many states are in the store (a table sized for --max-states, a "
+                    "shorter search: what the size of the closed set's table costs)")
     args = ap.parse_args()
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.search import BreadthFirstSearch
@@ -50,9 +54,12 @@ def main():
     d = os.path.join(ROOT, "pushworld_amd", "data", "puzzles")
     out = {}
     for rel in ("level1/2 Obstacle.pwp", "level1/Choose Wisely.pwp", "level2/Pull Dont Push.pwp", "level4/Four Pistons.pwp"):
+        if args.only and args.only not in rel:
+            continue
         with open(os.path.join(d, rel)) as f:
             text = f.read()
         pz = PushWorldPuzzle(text=text, order="cpp")
+        pz._engine().set_option("search_keys", args.keys)
         if args.groups:
             pz._engine().set_option("step_lane_batch", "never")
         bfs = BreadthFirstSearch(pz, max_states=args.max_states)
@@ -67,6 +74,9 @@ def main():
                 info = bfs.expand()
                 if info.goal_index >= 0:
                     status = "solved"
+                    break
+                if args.stop_at and bfs.total_states >= args.stop_at:
+                    status = "stopped"
                     break
         except ValueError:
             status = "store full"
