@@ -49,6 +49,24 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+# which kernel sources a configuration's PMC record describes (its dominant kernel's translation-unit pieces): a record stays
+# valid while THESE files are unchanged -- a tweak to the search kernels does not invalidate the render records
+_RENDER_SRC = ("pw_render_kernels.inc", "pw_zone.h", "pw_format.h")
+_STEP_SRC = ("pw_step_kernels.inc", "pw_format.h")
+KEY_SOURCES = {"C3_f32_ppc3": _RENDER_SRC, "C3_f32_ppc20_8192": _RENDER_SRC, "C4_u8_ppc3": _RENDER_SRC,
+               "C4_state": _STEP_SRC, "C4_rollout": _STEP_SRC, "C2_step": _STEP_SRC, "C2_rollout": _STEP_SRC,
+               "C5_2_obstacle": _STEP_SRC, "C5_pull_dont_push": _STEP_SRC, "C5_four_pistons": _STEP_SRC}
+
+
+def key_sha(config_key):
+    """sha256 over the source files the record of ``config_key`` depends on."""
+    h = hashlib.sha256()
+    for name in KEY_SOURCES.get(config_key, ()):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(config_key, units_per_launch):
     """(traffic bytes per launch, source string) from profiles/pmc_kernels_latest.json when it was measured on this
     kernel source and launch size; (None, why) otherwise."""
@@ -61,8 +79,10 @@ def pmc_traffic(config_key, units_per_launch):
     ent = rec.get("configs", {}).get(config_key)
     if not ent:
         return None, "profiles/pmc_kernels_latest.json has no record for " + config_key
-    if rec.get("csrc_sha16") != csrc_sha():
-        return None, "profiles/pmc_kernels_latest.json is stale (measured on another version of pushworld_amd/csrc); re-run tools/collect_profiles.sh"
+    current = ent.get("source_sha16") == key_sha(config_key) if "source_sha16" in ent else rec.get("csrc_sha16") == csrc_sha()
+    if not current:
+        return None, ("the record of " + config_key + " in profiles/pmc_kernels_latest.json is stale (measured on another version of "
+                      + ", ".join(KEY_SOURCES.get(config_key, ("pushworld_amd/csrc",))) + "); re-run tools/collect_profiles.sh")
     if int(ent.get("units_per_launch", -1)) != int(units_per_launch):
         return None, f"record is for {ent.get('units_per_launch')} units per launch, this run has {units_per_launch}"
     return ent["hbm_bytes_per_launch"], (f"recorded: profiles/pmc_kernels_latest.json ({ent.get('kernel_symbol')}; rocprofv3 --pmc FETCH_SIZE / "

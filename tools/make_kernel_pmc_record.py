@@ -5,7 +5,8 @@ read as 64 bytes on gfx950: doubled), one record per configuration of tools/conf
 
     python tools/make_kernel_pmc_record.py SOURCE  KEY:KERNEL_SUBSTRING:UNITS_PER_LAUNCH:FETCH_DB:WRITE_DB [...] > profiles/pmc_kernels_latest.json
 
-``UNITS_PER_LAUNCH`` selects the dispatches (grid sizes differ between the single-step launches and the rollouts of one
+``--merge=FILE`` first: records of FILE whose kernel sources (tools/config_suite.py: KEY_SOURCES) are unchanged are kept, so a
+collection only has to re-measure what changed.  ``UNITS_PER_LAUNCH`` selects the dispatches (grid sizes differ between the single-step launches and the rollouts of one
 profiled run: only dispatches whose duration-ordered position matches are not needed -- the caller passes one database pair per
 launch shape).  The record carries the sha of pushworld_amd/csrc: bench.py copies a record into its line only for the source
 it was measured on."""
@@ -30,17 +31,21 @@ def mean_counter(db, kernel, counter, grid=None):
 
 
 def main():
-    from tools.config_suite import csrc_sha
+    from tools.config_suite import csrc_sha, key_sha
     from tools.make_pmc_record import git_head
 
     source = sys.argv[1]
     configs = {}
     specs = sys.argv[2:]
-    if specs and specs[0].startswith("--merge="):  # keep the records of an earlier file of the SAME kernel source
-        with open(specs[0].split("=", 1)[1]) as f:
-            old = json.load(f)
-        if old.get("csrc_sha16") == csrc_sha():
-            configs.update(old.get("configs", {}))
+    if specs and specs[0].startswith("--merge="):  # keep the records of an earlier file whose kernel sources are unchanged
+        try:
+            with open(specs[0].split("=", 1)[1]) as f:
+                old = json.load(f)
+        except (OSError, ValueError):
+            old = {}
+        for key, ent in old.get("configs", {}).items():
+            if ent.get("source_sha16") == key_sha(key):
+                configs[key] = ent
         specs = specs[1:]
     for spec in specs:
         parts = spec.split(":")
@@ -54,7 +59,7 @@ def main():
             continue
         configs[key] = {"kernel_symbol": f[0], "units_per_launch": int(units), "hbm_bytes_per_launch": (2.0 * f[1] + w[1]) * 1024.0 * mult,
                         "write_size_kb": w[1], "fetch_size_kb_raw": f[1], "dispatches": [f[2], w[2]], "grids": f[3],
-                        "dispatches_per_call": mult}
+                        "dispatches_per_call": mult, "source_sha16": key_sha(key), "collected_by": source, "git_head": git_head()}
     print(json.dumps({"configs": configs, "source": source, "csrc_sha16": csrc_sha(), "git_head": git_head(),
                       "note": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, --kernel-trace only), mean over the "
                               "dispatches of the kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B)"},

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Copies what tools/collect_profiles.sh left under gpurun_out/prof_<tag>/ (scratch) into profiles/ (tracked):
+
+    python tools/publish_profiles.py r05
+
+  <name>_summary.txt        -> profiles/<tag>_<name>.txt          (rocprofv3 kernel-trace / PMC summaries)
+  bench.json, bench_full.json, trace_bench_line.json, bench_search.json
+                            -> profiles/<tag>_bench.json (the <= 4 KB line), <tag>_bench_full.json, <tag>_trace_bench_line.json, <tag>_search.json
+  pmc_kernels_latest.json, pmc_render_latest.json (when re-collected)   -> profiles/ (same names)
+"""
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    n = 0
+    for name in sorted(os.listdir(src)):
+        p = os.path.join(src, name)
+        if name.endswith("_summary.txt") and os.path.getsize(p) > 0:
+            shutil.copyfile(p, os.path.join(dst, f"{tag}_{name[:-len('_summary.txt')]}.txt"))
+            n += 1
+    for name, out in (("bench.json", f"{tag}_bench.json"), ("bench_full.json", f"{tag}_bench_full.json"),
+                      ("trace_bench_line.json", f"{tag}_trace_bench_line.json"), ("bench_search.json", f"{tag}_search.json"),
+                      ("pmc_kernels_latest.json", "pmc_kernels_latest.json"), ("pmc_render_latest.json", "pmc_render_latest.json")):
+        p = os.path.join(src, name)
+        if os.path.exists(p) and os.path.getsize(p) > 2:
+            if name == "bench.json":  # only the JSON line (stdout may carry warnings of libraries)
+                with open(p) as f:
+                    lines = [l for l in f if l.startswith("{") and '"metric"' in l]
+                if lines:
+                    with open(os.path.join(dst, out), "w") as f:
+                        f.write(lines[-1])
+                    n += 1
+                continue
+            shutil.copyfile(p, os.path.join(dst, out))
+            n += 1
+    print(f"{n} files published to profiles/ as {tag}_*")
+
+
+if __name__ == "__main__":
+    main()
