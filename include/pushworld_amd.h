@@ -330,12 +330,15 @@ int pw_engine_tune_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* p
  *                       engine its tuned launch configuration; returns the tuner's index (>= 0).  candidate_ms (host
  *                       float [max_candidates], may be NULL) receives every candidate's screened time, *tried how many
  *                       were made.
+ *   (not shareable)     such a buffer is a hipMemMap range: hipIpcGetMemHandle does not apply to it.  A caller that shares
+ *                       observations with other processes owns the buffer (hipMalloc) and calls pw_engine_tune_render on it.
  *   pw_obs_free         unmaps the buffer, releases its memory to the device and frees its address range (synchronises
  *                       the device first).  pw_engine_destroy frees what is left.
  * Address ranges are never handed out twice within a process (a range freed and reserved again showed stale contents
- * through views of the old one on this runtime): they are taken upwards from 32 TiB, ~20 000 buffers of the C3 size (one per
- * candidate) in a 47-bit address space; after that the calls fail with PW_ENOMEM and the caller uses a buffer of its own
- * (VecPushWorld does, with a warning). */
+ * through views of the old one on this runtime): they are taken upwards from 32 TiB behind a watermark (O(1) state; a range
+ * the runtime places below it is parked -- at most 8 per request -- and given back at process exit), ~20 000 buffers of the C3
+ * size (one per candidate) in a 47-bit address space; after that the calls fail with PW_ENOMEM and the caller uses a buffer of
+ * its own (VecPushWorld does, with a warning). */
 int pw_obs_alloc(PwEngine* e, int32_t batch, void** obs);
 int pw_obs_alloc_tuned(PwEngine* e, const int32_t* puzzle_id, const int8_t* pos, int32_t batch, int32_t max_candidates,
                        void** obs, float* candidate_ms, int32_t* tried, void* stream);
