@@ -178,3 +178,41 @@ def test_first_step_render_of_an_engine_is_capturable(golden):
     ref.reset()
     ref.step(acts[0])
     assert torch.equal(ref.pos, st["pos"]) and torch.equal(ref.obs, view)
+
+
+def test_plans_longer_than_one_launch_continue_from_the_last_state(golden):
+    """``PW_PLAN_MAX_ACTIONS`` (65 536) is a per-launch limit, not a limit of ``is_valid_plan`` / ``render_plan`` (the reference
+    accepts plans of any length, puzzle.py:413-424, 471-506): 150 000 random actions through ``plan_states`` -- three launches,
+    each continuing from the last state of the one before -- against the C oracle stepped action by action; the device copy
+    of the states (what ``render_plan`` draws from) holds the same rows."""
+    import torch
+
+    from oracle import c_oracle
+    from pushworld_amd import _capi
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    text = golden.text("bench:level1/2 Obstacle.pwp")
+    pz = PushWorldPuzzle(text=text)
+    oz = c_oracle.COraclePuzzle(text)
+    T = 150_000
+    assert T > 2 * _capi.PLAN_MAX_ACTIONS
+    acts = np.random.default_rng(21).integers(0, 4, size=T, dtype=np.uint8)
+    eng = pz._engine()
+    dev = torch.zeros((T + 1, eng.np, 2), dtype=torch.int8, device=eng.device)
+    torch.cuda.current_stream(eng.device).synchronize()
+    states, goals = eng.plan_states(0, bytes(acts), dev_states=dev)
+    s = oz.initial_state
+    n = oz.num_movables
+    check_at = set(range(0, T + 1, 997)) | {_capi.PLAN_MAX_ACTIONS - 1, _capi.PLAN_MAX_ACTIONS, _capi.PLAN_MAX_ACTIONS + 1,
+                                             2 * _capi.PLAN_MAX_ACTIONS, 2 * _capi.PLAN_MAX_ACTIONS + 1, T}
+    goal_state = tuple(oz.py.goal_state)
+    for t in range(T + 1):
+        if t in check_at:
+            assert tuple(map(tuple, states[t].tolist())) == tuple(s), t
+            assert bool(goals[t]) == (tuple(s[1 : 1 + len(goal_state)]) == goal_state), t
+        if t < T:
+            s = oz.get_next_state(s, int(acts[t]))
+    got_dev = dev.cpu().numpy()
+    assert (got_dev[:, :n] == states).all() and (got_dev[:, n:] == 0).all()
+    # and through the reference's own entry point: a long walk is not a valid plan, but it is answered, not refused
+    assert pz.is_valid_plan([int(a) for a in acts[:70_000]]) in (True, False)
