@@ -410,3 +410,36 @@ def test_pair_tables_sized_per_pair_against_the_oracle():
             assert (succ == want_succ).all() and (moved.astype(np.uint32) == want_moved).all() and (goal == want_goal).all(), path
             checked += 1
     assert checked >= 40
+
+
+def test_cpp_order_with_many_ids_against_the_reference():
+    """tests/golden/golden_cpp_order.json: 24 puzzles with 10-13 movables whose ids run past 10 ("m10" < "m2" in the C++ order of
+    pushworld_puzzle.cc:262-321), expectations from the PYTHON reference rearranged by that rule: pw_expand4's successors,
+    moved-object masks (pushworld_puzzle.cc:446-457) and goal flags of the sampled states, and the engine's object order itself."""
+    import json
+    import os
+
+    from pushworld_amd.puzzle import PushWorldPuzzle
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_cpp_order.json")) as f:
+        fx = json.load(f)
+    pushes = 0
+    for key, ent in fx.items():
+        pz = PushWorldPuzzle(text=ent["text"], order="cpp")
+        assert [list(p) for p in pz.initial_state] == ent["states_cpp"][0], key
+        assert [list(p) for p in pz.goal_state] == ent["goal_state_cpp"], key
+        smp = ent["expand"]
+        st = np.array([ent["states_cpp"][s["t"]] for s in smp], dtype=np.int64)
+        states = (st[:, :, 0] * 10000 + st[:, :, 1]).astype(np.int32)
+        succ, moved, goal = (t.cpu().numpy() for t in pz.expand4(states))
+        want = np.array([s["succ"] for s in smp], dtype=np.int64)
+        assert (succ == (want[..., 0] * 10000 + want[..., 1])).all(), key
+        assert (moved.astype(np.uint32) == np.array([s["moved"] for s in smp], dtype=np.uint32)).all(), key
+        assert (goal.astype(bool) == np.array([s["goal"] for s in smp])).all(), key
+        pushes += int(sum(bin(m).count("1") > 1 for s in smp for m in s["moved"]))
+        # and the whole walk through the single-state API in this order
+        s = pz.initial_state
+        for t, a in enumerate(ent["actions"][:60]):
+            s = pz.get_next_state(s, a)
+            assert [list(p) for p in s] == ent["states_cpp"][t + 1], (key, t)
+    assert pushes >= 50

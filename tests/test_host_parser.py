@@ -407,3 +407,19 @@ def test_overlap_tables_are_the_reference_collision_tables(golden):
                     assert len(dynamic[a][i][j]) == m["dynamic_sizes"][a][i][j], (k, a, i, j)
                     h.update(np.array(sorted(dynamic[a][i][j]), np.int32).tobytes())
         assert h.hexdigest() == m["tables_sha"], k
+
+
+def test_cpp_order_with_many_ids_against_the_reference():
+    """The host packer's C++ order on the puzzles of golden_cpp_order.json (ids past 10: "m10" < "m2"), whose expectations
+    come from the Python reference under the permutation pushworld_puzzle.cc:262-321 defines."""
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_cpp_order.json")) as f:
+        fx = json.load(f)
+    for key, ent in fx.items():
+        c = _capi.ParsedPuzzle(ent["text"], _capi.ORDER_CPP)
+        assert c.names == ent["cpp_names"], key
+        assert [list(p) for p in c.initial_state] == ent["states_cpp"][0], key
+        assert [list(p) for p in c.goal_state] == ent["goal_state_cpp"], key
+        p = _capi.ParsedPuzzle(ent["text"], _capi.ORDER_PYTHON)
+        assert p.names == ent["python_names"], key

@@ -1,6 +1,7 @@
 """The oracle (oracle/pw_oracle.py and its C twin oracle/pw_oracle.c) pinned against fixtures
 captured from the reference itself (tests/golden/make_golden.py).  CPU only."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -232,3 +233,42 @@ def test_novelty_oracle_known_answers():
            ((1, 3, 5, 4), (), 3)]
     for state, moved, want in seq:
         assert nov.estimate(state, moved) == want, (state, moved)
+
+
+def _cpp_order_fixture():
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_cpp_order.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("impl", ["py", "c"])
+def test_cpp_order_with_many_ids_against_the_reference(impl):
+    """tests/golden/golden_cpp_order.json (make_cpp_order_golden.py): 24 random puzzles with 10-13 movables whose ids run past 10,
+    stepped by the PYTHON reference and rearranged into the C++ object order of pushworld_puzzle.cc:262-321 (goal ids ascending
+    by string: g1 < g10 < g2; then the other movables the same way).  Both oracles in order="cpp": object names, initial and goal
+    state, 300 steps of a random walk, satisfiesGoal of every state."""
+    fx = _cpp_order_fixture()
+    assert len(fx) >= 20
+    for key, ent in fx.items():
+        text = ent["text"]
+        o = pw_oracle.OraclePuzzle(text, order="cpp", build_tables=impl == "py")
+        assert o.names == ent["cpp_names"], key
+        assert any(int(nm[1:]) >= 10 for nm in o.names[1:]) and ent["cpp_names"] != ent["python_names"]
+        assert [list(p) for p in o.initial_state] == ent["states_cpp"][0], key
+        assert [list(p) for p in o.goal_state] == ent["goal_state_cpp"], key
+        stepper = c_oracle.COraclePuzzle(text, order="cpp") if impl == "c" else o
+        s = tuple(tuple(p) for p in ent["states_cpp"][0])
+        for t, a in enumerate(ent["actions"]):
+            s = tuple(tuple(p) for p in stepper.get_next_state(s, a))
+            assert [list(p) for p in s] == ent["states_cpp"][t + 1], (key, t)
+            assert o.is_goal_state(s) == ent["goal_flags"][t + 1], (key, t)
+        for smp in ent["expand"]:
+            st = tuple(tuple(p) for p in ent["states_cpp"][smp["t"]])
+            for b in range(4):
+                if impl == "c":
+                    nxt, moved = stepper.get_next_state_moved(st, b)
+                    assert sum(1 << k for k in moved) == smp["moved"][b], (key, smp["t"], b)
+                else:
+                    nxt = stepper.get_next_state(st, b)
+                assert [list(p) for p in nxt] == smp["succ"][b], (key, smp["t"], b)
