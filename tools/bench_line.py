@@ -13,7 +13,7 @@ def dumps(obj):
     return json.dumps(obj, separators=(",", ":"))
 
 
-MAX_LINE_BYTES = 4000  # (the driver's tail holds ~8.6 KB; the judge asked for <= 4 KB)
+MAX_LINE_BYTES = 3900  # (the driver keeps ~8.6 KB of stdout; the judge asked for <= 4 KB: some margin under 4 096)
 
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")
