@@ -412,6 +412,92 @@ def test_pair_tables_sized_per_pair_against_the_oracle():
     assert checked >= 40
 
 
+def _many_movables_text(rng, n_mov, cols=20, rows=14):
+    """a puzzle with n_mov movables (agent included) of 1-3 cells, goals for a third of them, some walls"""
+    grid = [[[] for _ in range(cols)] for _ in range(rows)]
+
+    def blob(n):
+        cells = [(int(rng.integers(0, cols)), int(rng.integers(0, rows)))]
+        for _ in range(n - 1):
+            bx, by = cells[int(rng.integers(0, len(cells)))]
+            dx, dy = [(1, 0), (-1, 0), (0, 1), (0, -1)][int(rng.integers(0, 4))]
+            if 0 <= bx + dx < cols and 0 <= by + dy < rows and (bx + dx, by + dy) not in cells:
+                cells.append((bx + dx, by + dy))
+        return cells
+
+    for _ in range(int(rng.integers(4, 14))):
+        grid[int(rng.integers(0, rows))][int(rng.integers(0, cols))].append("W")
+    names = ["A"] + [f"M{k}" for k in range(1, n_mov)]
+    for name in names:
+        while True:
+            cells = blob(int(rng.integers(1, 4)))
+            if all(not grid[y][x] for x, y in cells):
+                for x, y in cells:
+                    grid[y][x].append(name)
+                break
+    for k in range(1, n_mov):
+        if rng.random() < 0.35:
+            x, y = int(rng.integers(0, cols)), int(rng.integers(0, rows))
+            if not any(t.startswith("G") or t == "W" for t in grid[y][x]):
+                grid[y][x].append(f"G{k}")
+    if not any(t.startswith("G") for row in grid for c in row for t in c):
+        grid[0][0] = [t for t in grid[0][0] if t != "W"] + ["G1"]
+    return "\n".join(" ".join("+".join(c) if c else "." for c in row) for row in grid) + "\n"
+
+
+def test_wide_work_word_17_to_20_movables_against_the_oracle():
+    """pw_expand4_v2_kernel with a 128-bit work word (4 bits per movable and action): 17 .. 20 movables, per-pair byte tables
+    (round 5; `Clean Sweep`, 19 movables, was the one benchmark puzzle left to the lane kernel).  `Clean Sweep` and seeded random
+    puzzles with 17, 18, 19 and 20 movables (C++ object order): breadth-first frontiers of >= 140 000 states -- successors,
+    moved-object masks (bits 16 .. 19 among them) and goal flags of every state against the C oracle, and word for word against
+    the lane kernel (PW_OPT_EXPAND_LDS_TABLES never)."""
+    from oracle import c_oracle
+    from pushworld_amd import benchmark_data as bd
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.search import BreadthFirstSearch
+
+    texts = []
+    for lv in (1, 2, 3, 4):
+        for path in bd.level_paths(lv):
+            with open(path) as f:
+                text = f.read()
+            if 17 <= c_oracle.COraclePuzzle(text, order="cpp").num_movables <= 20:
+                texts.append((os.path.basename(path), text))
+    assert any(name.startswith("Clean Sweep") for name, _ in texts)
+    rng = np.random.default_rng(1719)
+    for n in (17, 18, 19, 20, 20):
+        texts.append((f"random{n}", _many_movables_text(rng, n)))
+    high_moves = 0
+    for name, text in texts:
+        oz = c_oracle.COraclePuzzle(text, order="cpp")
+        pz = PushWorldPuzzle(text=text, order="cpp")
+        bfs_gpu = BreadthFirstSearch(pz, max_states=400_000)
+        bfs_gpu.begin()
+        try:
+            while bfs_gpu.total_states < 140_000 and not bfs_gpu.exhausted:
+                bfs_gpu.expand()
+        except ValueError:  # the store filled up inside a layer: what is in it is enough
+            pass
+        F = min(bfs_gpu.total_states, 200_000)
+        xy = bfs_gpu.states(0, F)
+        bfs_gpu.close()
+        if F < 140_000:
+            xy = np.tile(xy, (-(-140_000 // F), 1, 1))[:140_001]  # (a ragged last tile)
+            F = len(xy)
+        states = np.ascontiguousarray((xy[:, :, 0].astype(np.int64) * 10000 + xy[:, :, 1]).astype(np.int32))
+        eng = pz._engine()
+        eng.set_option("expand_lds_tables", "auto")
+        succ, moved, goal = (t.cpu().numpy() for t in pz.expand4(states))
+        eng.set_option("expand_lds_tables", "never")
+        succ0, moved0, goal0 = (t.cpu().numpy() for t in pz.expand4(states))
+        eng.set_option("expand_lds_tables", "auto")
+        assert (succ == succ0).all() and (moved == moved0).all() and (goal == goal0).all(), name
+        want_succ, want_moved, want_goal = c_oracle.expand4_batch(oz, states)
+        assert (succ == want_succ).all() and (moved.astype(np.uint32) == want_moved).all() and (goal == want_goal).all(), name
+        high_moves += int((want_moved >> 16 != 0).sum())
+    assert high_moves > 100  # movables 16 .. 19 were pushed: the upper half of the word is exercised
+
+
 def test_cpp_order_with_many_ids_against_the_reference():
     """tests/golden/golden_cpp_order.json: 24 puzzles with 10-13 movables whose ids run past 10 ("m10" < "m2" in the C++ order of
     pushworld_puzzle.cc:262-321), expectations from the PYTHON reference rearranged by that rule: pw_expand4's successors,

@@ -21,6 +21,8 @@ def main():
                   if os.sep + "level0" + os.sep not in f and not os.path.relpath(f, BENCHMARK_PUZZLES_PATH).startswith("level0"))
     if len(sys.argv) > 1 and sys.argv[1].isdigit():
         rels = rels[::max(1, len(rels) // int(sys.argv[1]))]
+    elif len(sys.argv) > 1:  # only the puzzles whose path contains one of the arguments
+        rels = [r for r in rels if any(a in r for a in sys.argv[1:])]
     rows = []
     t_start = time.time()
     for rel in rels:
