@@ -298,6 +298,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       w_i + w_j + 2 bytes) where the set-wide 2 max_h + 2 by 2 max_w + 2 tables exceed 16 KB, 7 .. 16
                                       movables --, 2 never (set-wide tables, or the lane kernel where those do not fit LDS) */
 #define PW_OPT_STEP_QUAD16_PUZZLES 32 /* read-only: puzzles of the set with such a record */
+#define PW_OPT_MAILBOX_MODE 35       /* pw_mailbox_open (A/B runs): bits 0-1 who reads the host's word -- 0 every wavefront, 1 one wavefront per
+                                      workgroup, 2 ONE wavefront, which passes it on through device memory; bit 2 (+4): system-scope
+                                      fences around a step instead of system-scope accesses.  Same results. */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order
@@ -439,6 +442,41 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
                int8_t* pos, int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
                uint8_t* truncated, double* reward_hist, uint8_t* terminated_hist,
                uint8_t* truncated_hist, int32_t batch, uint32_t flags, void* stream);
+
+/* RESIDENT stepping of a small state-only batch ("mailbox"): gym_env.py:188-226 for a host that needs every step's verdicts
+ * before it chooses the next actions, without a kernel launch and a stream synchronisation per step.  pw_mailbox_open starts a
+ * kernel that keeps the batch in registers and waits; pw_mailbox_post hands it the actions of ONE step (a word in pinned memory:
+ * no launch); the kernel performs exactly what pw_step(flags) performs -- the arrays given to pw_mailbox_open receive what
+ * pw_step would have written, after every step -- and leaves the step's reward / terminated / truncated in pinned host memory,
+ * which pw_mailbox_wait returns once the step is complete.  Up to `ring` steps may be posted ahead of the last complete one
+ * (pw_mailbox_post waits beyond that); the pointers a wait returns stay valid until `ring` more steps have been posted.
+ *   - sets whose puzzles all fit 8 x 8 cells with at most 8 movables (PW_OPT_STEP_BOARD_SET = 1: the Level-0 families), batches of
+ *     up to 65 536 environments; PW_ELIMIT otherwise;
+ *   - puzzle_id is read once, at the open: episodes restart (PW_STEP_AUTORESET) on the same puzzle;
+ *   - everything queued on other streams for the arrays must be complete before the open, and while the mailbox is open the
+ *     engine's other stepping calls fail (the environments live in the resident kernel); pw_counters is current after the close;
+ *   - `actions`: device memory, or host memory (actions_on_host != 0: copied into a pinned staging slot, read by the kernel
+ *     across the link);
+ *   - the kernel ends by pw_mailbox_close, or BY ITSELF after idle_ms (0 = 1 000) without a post: a resident kernel would
+ *     otherwise hold every device-wide synchronisation (hipDeviceSynchronize, torch.cuda.synchronize) for ever.  pw_mailbox_post
+ *     fails with PW_EDEVICE once more than idle_ms / 2 have passed since the previous post (the mailbox has expired: close it
+ *     and open a new one; the arrays hold the state after the last complete step).
+ * Measured (C2, 4 096 environments, tools/bench_mailbox.py): see DESIGN.md K1f. */
+typedef struct PwMailbox PwMailbox;
+int pw_mailbox_open(PwEngine* e, const int32_t* puzzle_id, int8_t* pos, int32_t* steps, double* reward, int8_t* dgoals,
+                    uint8_t* terminated, uint8_t* truncated, int32_t batch, uint32_t flags, int32_t ring /* 0 = 8 */,
+                    int32_t idle_ms /* 0 = 1000 */, PwMailbox** out);
+int pw_mailbox_post(PwMailbox* m, const uint8_t* actions, int32_t actions_on_host, uint64_t* seq /* out: 1, 2, ... */);
+int pw_mailbox_wait(PwMailbox* m, uint64_t seq, const double** reward, const uint8_t** terminated, const uint8_t** truncated);
+/* num_steps posts from one uint8 [num_steps][B] array with at most `ahead` steps in flight (<= 1: every step waits for the one
+ * before, the cadence of a host that chooses the next actions from a step's verdicts); returns when all are complete. */
+int pw_mailbox_run(PwMailbox* m, const uint8_t* actions, int32_t num_steps, int32_t actions_on_host, int32_t ahead,
+                   uint64_t* last_seq);
+/* pw_mailbox_close_profile: as the close, and (profile: int64 [8], or NULL) [0] steps completed, [1] how the kernel ended (2 stop
+ * word, 3 idle limit), [2..6] ticks of the device's constant clock that wavefront 0 spent waiting for the word / reading its
+ * actions / stepping / storing / counting itself in, [7] that clock's kHz. */
+int pw_mailbox_close_profile(PwMailbox* m, int64_t* profile);
+int pw_mailbox_close(PwMailbox* m);
 
 /* puzzle.py:426-469 render() + env_utils.py:44-91 padding (+ /255 for PW_OBS_F32).
  * obs: device buffer, env e at obs + e * env_stride_bytes (multiple of 16, base 16 B aligned). */

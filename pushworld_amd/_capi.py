@@ -14,6 +14,7 @@ from ctypes import POINTER, c_char_p, c_int, c_int32, c_int64, c_size_t, c_uint3
 # torch first: it loads its bundled HIP runtime (SONAME libamdhip64.so.7); loading our
 # library afterwards binds to that same runtime, so tensor.data_ptr() values and
 # torch.cuda streams are valid inside the kernels' process-wide HIP context.
+import numpy as np
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -111,6 +112,16 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_void_p, c_int32, c_uint32, c_void_p],
     ),
+    "pw_mailbox_open": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint32, c_int32, c_int32,
+         POINTER(c_void_p)],
+    ),
+    "pw_mailbox_post": (c_int, [c_void_p, c_void_p, c_int32, POINTER(ctypes.c_uint64)]),
+    "pw_mailbox_wait": (c_int, [c_void_p, ctypes.c_uint64, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "pw_mailbox_run": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(ctypes.c_uint64)]),
+    "pw_mailbox_close_profile": (c_int, [c_void_p, POINTER(c_int64)]),
+    "pw_mailbox_close": (c_int, [c_void_p]),
     "pw_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_step_render": (
         c_int,
@@ -195,6 +206,7 @@ OPTIONS = {
     "search_keys": 33,         # closed set of the searches created afterwards: 0 / "fingerprint" (default), 1 / "exact" 63-bit keys where they fit
     "expand_pair_dims": 34,    # pw_expand4 (tables in LDS): 0 / "auto" pair tables sized per pair where the uniform ones exceed 16 KB, 2 / "never"
     "step_quad16_puzzles": 32, # read-only: puzzles of the set that fit
+    "mailbox_mode": 35,        # pw_mailbox_open: 0 / 1 / 2 who polls the host's word (every wavefront / one per workgroup / one), + 4 fences
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2,
@@ -426,6 +438,103 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 if _raw_stream is None:  # pragma: no cover -- older torch
     def _raw_stream(device_index):
         return torch.cuda.current_stream(device_index).cuda_stream
+
+
+class Mailbox:
+    """``pw_mailbox_*`` (include/pushworld_amd.h): a resident kernel that steps a small state-only batch whenever the host posts
+    the actions of a step -- no launch, no stream synchronisation.  ``post`` returns the step's number, ``wait`` the verdicts of
+    that step as numpy views of pinned host memory (valid until ``ring`` more steps have been posted), ``step`` does both.
+    The arrays given here receive after every step what ``pw_step`` would have written.  A context manager: the kernel ends at
+    ``close`` (or by itself after ``idle_ms`` without a post -- ``post`` then raises RuntimeError)."""
+
+    def __init__(self, engine, puzzle_id, pos, steps, reward, dgoals, terminated, truncated, flags=0, ring=8, idle_ms=1000):
+        self.engine = engine
+        self.batch = int(pos.shape[0])
+        self._keep = (puzzle_id, pos, steps, reward, dgoals, terminated, truncated)
+        torch.cuda.current_stream(engine.device).synchronize()  # what was queued for these arrays is complete
+        handle = c_void_p()
+        check(lib.pw_mailbox_open(engine.handle, _ptr(puzzle_id), _ptr(pos), _ptr(steps), _ptr(reward), _ptr(dgoals),
+                                  _ptr(terminated), _ptr(truncated), self.batch, flags, ring, idle_ms, ctypes.byref(handle)))
+        self.handle = handle
+        self._seq = ctypes.c_uint64()
+        self._out = (c_void_p(), c_void_p(), c_void_p())
+
+    def post(self, actions) -> int:
+        """``actions``: uint8 [B], a numpy array (host) or a tensor on the engine's device (complete: nothing is queued behind
+        a stream here)."""
+        if self.handle is None:
+            raise RuntimeError("the mailbox is closed")
+        if isinstance(actions, np.ndarray):
+            if actions.dtype != np.uint8 or actions.shape != (self.batch,) or not actions.flags.c_contiguous:
+                raise ValueError("actions must be a contiguous uint8 array of shape [num_envs]")
+            check(lib.pw_mailbox_post(self.handle, c_void_p(actions.ctypes.data), 1, ctypes.byref(self._seq)))
+        else:
+            if actions.dtype != torch.uint8 or tuple(actions.shape) != (self.batch,) or not actions.is_contiguous() \
+                    or actions.device != self.engine.device:
+                raise ValueError("actions must be a contiguous uint8 tensor of shape [num_envs] on the engine's device")
+            check(lib.pw_mailbox_post(self.handle, _ptr(actions), 0, ctypes.byref(self._seq)))
+        return self._seq.value
+
+    def wait(self, seq: int):
+        if self.handle is None:
+            raise RuntimeError("the mailbox is closed")
+        r, t, u = self._out
+        check(lib.pw_mailbox_wait(self.handle, seq, ctypes.byref(r), ctypes.byref(t), ctypes.byref(u)))
+        B = self.batch
+        return (np.ctypeslib.as_array(ctypes.cast(r, POINTER(ctypes.c_double)), (B,)),
+                np.ctypeslib.as_array(ctypes.cast(t, POINTER(ctypes.c_uint8)), (B,)),
+                np.ctypeslib.as_array(ctypes.cast(u, POINTER(ctypes.c_uint8)), (B,)))
+
+    def step(self, actions):
+        return self.wait(self.post(actions))
+
+    def run(self, actions, ahead: int = 1) -> int:
+        """``pw_mailbox_run``: the steps of a uint8 [T, B] array (numpy: host, tensor: device) with at most ``ahead`` in flight;
+        returns the number of the last step (``wait`` gives the verdicts of the last ``ring`` steps)."""
+        if self.handle is None:
+            raise RuntimeError("the mailbox is closed")
+        host = isinstance(actions, np.ndarray)
+        if host:
+            ok = actions.dtype == np.uint8 and actions.ndim == 2 and actions.shape[1] == self.batch and actions.flags.c_contiguous
+            ptr = c_void_p(actions.ctypes.data)
+        else:
+            ok = actions.dtype == torch.uint8 and actions.dim() == 2 and actions.shape[1] == self.batch and actions.is_contiguous() \
+                and actions.device == self.engine.device
+            ptr = _ptr(actions)
+        if not ok:
+            raise ValueError("actions must be a contiguous uint8 array / tensor of shape [T, num_envs]")
+        check(lib.pw_mailbox_run(self.handle, ptr, int(actions.shape[0]), 1 if host else 0, int(ahead), ctypes.byref(self._seq)))
+        return self._seq.value
+
+    def close(self, profile: bool = False):
+        """Ends the kernel.  ``profile=True``: returns microseconds per step that wavefront 0 spent waiting for the host's word,
+        reading its actions, stepping, storing, and counting itself in (``pw_mailbox_close_profile``)."""
+        if self.handle is None:
+            return None
+        handle, self.handle = self.handle, None
+        if not profile:
+            check(lib.pw_mailbox_close(handle))
+            return None
+        raw = (c_int64 * 8)()
+        check(lib.pw_mailbox_close_profile(handle, raw))
+        out = {"steps": raw[0], "ended_by": {2: "stop", 3: "idle"}.get(raw[1], raw[1])}
+        if raw[0] > 0 and raw[7] > 0:
+            for i, n in enumerate(("wait_for_word", "read_actions", "step", "store", "arrive")):
+                out[n + "_us"] = round(raw[2 + i] / raw[7] * 1e3 / raw[0], 3)
+        return out
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class _DLDevice(ctypes.Structure):
@@ -750,6 +859,10 @@ class Engine:
         check(lib.pw_rollout(self.handle, _ptr(puzzle_id), _ptr(actions), actions.shape[0], _ptr(pos), _ptr(steps),
                              _ptr(reward), _ptr(dgoals), _ptr(terminated), _ptr(truncated), _ptr(reward_hist),
                              _ptr(terminated_hist), _ptr(truncated_hist), pos.shape[0], flags, self._stream()))
+
+    def mailbox(self, puzzle_id, pos, steps, reward, dgoals, terminated, truncated, flags=0, ring=8, idle_ms=1000):
+        """``pw_mailbox_open``: the resident step kernel over these arrays (see :class:`Mailbox`)."""
+        return Mailbox(self, puzzle_id, pos, steps, reward, dgoals, terminated, truncated, flags, ring, idle_ms)
 
     def render(self, puzzle_id, pos, obs_storage):
         check(lib.pw_render(self.handle, _ptr(puzzle_id), _ptr(pos), _ptr(obs_storage), self.obs_stride,

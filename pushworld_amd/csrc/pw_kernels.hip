@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -94,6 +95,7 @@ struct PwObsBuf {
   std::vector<hipMemGenericAllocationHandle_t> handles;
 };
 
+struct PwMailbox;
 struct PwEngine {
   const PwPuzzleSet* set;
   PwEngineConfig cfg;
@@ -179,6 +181,8 @@ struct PwEngine {
   size_t lat_bytes;
   uint32_t lat_seq;        // completion word of the last launch
   std::mutex lat_mu;       // pw_next_state / pw_plan_states share lat_host and lat_seq: one call at a time per engine
+  PwMailbox* mailbox;     // the open resident step kernel of this engine (pw_mailbox_open), or NULL
+  int mailbox_mode;       // PW_OPT_MAILBOX_MODE
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)
@@ -352,5 +356,6 @@ struct PageRec {
 #include "pw_step_kernels.inc"
 #include "pw_render_kernels.inc"
 #include "pw_engine.inc"
+#include "pw_mailbox.inc"
 #include "pw_search.inc"
 #include "pw_generate.inc"

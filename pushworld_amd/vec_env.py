@@ -278,6 +278,19 @@ class VecPushWorld:
             return rh, th, uh
         return self.reward, self.terminated, self.truncated
 
+    def mailbox(self, ring: int = 8, idle_ms: int = 1000):
+        """Resident stepping (``pw_mailbox_open``) for hosts that need every step's verdicts before they choose the next actions:
+        ``with vec.mailbox() as mb: reward, terminated, truncated = mb.step(actions)`` -- numpy views of pinned host memory, a
+        few microseconds per step instead of a launch and a stream synchronisation.  Same semantics as ``step`` with
+        ``observation=None`` (this object's ``pos`` / ``steps`` / ``reward`` / ... tensors are kept up to date); only for sets of
+        puzzles that fit 8 x 8 cells, state only; ``step`` / ``rollout`` / ``reset`` of this object fail while it is open.  Bad
+        actions are flagged 0xFF in ``terminated`` / ``truncated`` and counted (``counters()['bad_actions']``) as in ``step``."""
+        if not self._has_reset:
+            raise RuntimeError("reset() must be called before step() can be called.")
+        self._obs_current = False
+        return self.engine.mailbox(self.puzzle_id, self.pos, self.steps, self.reward, self.dgoals, self.terminated, self.truncated,
+                                   self.flags, ring, idle_ms)
+
     def render(self):
         """Re-renders the current states into the observation buffer and returns it."""
         if self.obs is None:

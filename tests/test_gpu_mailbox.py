@@ -1,0 +1,168 @@
+"""-m gpu: the resident step kernel (pw_mailbox_*, K1f) against pw_step on a twin batch, step by step and bit for bit:
+positions, step counters, float64 rewards, terminated / truncated (with next-step autoreset, truncation, solved episodes from the
+puzzles' solution-like random play, and actions outside 0..3), the pinned host verdicts of every step, posts that run ahead of the
+waits, host and device actions, the counters after the close, the idle limit, and the refusals while a mailbox is open."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _pool(n):
+    from pushworld_amd import benchmark_data as bd
+
+    texts = [t for t in bd.level0_texts().values()]
+    small = []
+    for t in texts:
+        rows = [r for r in t.strip().splitlines()]
+        if len(rows) + 2 <= 8 and len(rows[0].split()) + 2 <= 8:
+            small.append(t)
+        if len(small) == n:
+            break
+    assert len(small) == n
+    return small
+
+
+def _twins(B, n_puzzles, max_steps, autoreset=True):
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    texts = _pool(n_puzzles)
+    ids = (np.arange(B, dtype=np.int64) * n_puzzles) // B
+    mk = lambda: VecPushWorld([PushWorldPuzzle(text=t) for t in texts], B, puzzle_ids=ids, max_steps=max_steps, observation=None,
+                              device=0, autoreset=autoreset)
+    a, b = mk(), mk()
+    assert a.engine.get_option("step_board_set") == 1
+    a.reset()
+    b.reset()
+    return a, b
+
+
+def _same_state(a, b):
+    import torch
+
+    torch.cuda.synchronize()
+    assert (a.pos == b.pos).all() and (a.steps == b.steps).all()
+    assert (a.terminated == b.terminated).all() and (a.truncated == b.truncated).all()
+    assert (a.reward.view(torch.int64) == b.reward.view(torch.int64)).all()
+
+
+@pytest.mark.parametrize("B,host_actions,mode", [(4096, True, 2), (4096, False, 2), (1000, True, 2), (37, False, 2), (20000, True, 2),
+                                                  (4096, True, 0), (3000, False, 1), (4096, False, 6), (700, True, 4), (5000, True, 5)])
+def test_mailbox_steps_equal_pw_step(B, host_actions, mode):
+    import torch
+
+    T = 160
+    a, b = _twins(B, 23, max_steps=25)
+    assert a.engine.get_option("mailbox_mode") == 2
+    a.engine.set_option("mailbox_mode", mode)  # who polls the host's word, fences or system-scope accesses: same results
+    rng = np.random.default_rng(B)
+    acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
+    acts[40, ::7] = 9      # outside Discrete(4)
+    acts[41, 3::11] = 255
+    acts_dev = torch.as_tensor(acts).to(a.device)
+    torch.cuda.synchronize()
+    ended = solved = 0
+    with a.mailbox() as mb:
+        for t in range(T):
+            r, te, tr = mb.step(acts[t] if host_actions else acts_dev[t])
+            _, r2, te2, tr2 = b.step(acts_dev[t])
+            assert (r.view(np.uint64) == r2.cpu().numpy().view(np.uint64)).all(), t
+            assert (te == te2.cpu().numpy()).all() and (tr == tr2.cpu().numpy()).all(), t
+            ok = te != 0xFF
+            ended += int(((te | tr) != 0)[ok].sum())
+            solved += int((te != 0)[ok].sum())
+            if t % 20 == 19 or t in (40, 41, 42):  # the device arrays after this step (the kernel is still resident)
+                assert (a.pos.cpu() == b.pos.cpu()).all() and (a.steps.cpu() == b.steps.cpu()).all(), t
+        with pytest.raises(ValueError):
+            a.step(acts_dev[0])  # the environments live in the resident kernel
+        with pytest.raises(ValueError):
+            a.reset()
+    _same_state(a, b)
+    ca, cb = a.counters(), b.counters()
+    assert ca == cb and ca["env_steps"] == B * T and ca["episodes_ended"] == ended and ca["episodes_solved"] == solved
+    # (actions outside 0..3 on the reset step of an episode are ignored, not counted)
+    assert 0 < ca["bad_actions"] <= len(acts[40, ::7]) + len(acts[41, 3::11]) and ended > B  # (truncations at 25 steps: several per env)
+    # ... and the batch carries on through ordinary launches
+    a.step(acts_dev[5])
+    b.step(acts_dev[5])
+    _same_state(a, b)
+
+
+def test_posts_ahead_of_the_waits_and_reopen():
+    import torch
+
+    B, T = 4096, 96
+    a, b = _twins(B, 5, max_steps=30)
+    acts = np.random.default_rng(3).integers(0, 4, size=(T, B), dtype=np.uint8)
+    acts_dev = torch.as_tensor(acts).to(a.device)
+    torch.cuda.synchronize()
+    want = []
+    for t in range(T):
+        _, r, te, tr = b.step(acts_dev[t])
+        want.append((r.cpu().numpy().copy(), te.cpu().numpy().copy(), tr.cpu().numpy().copy()))
+    for first, ring in ((0, 8), (T // 2, 2)):  # two mailboxes in turn over the same batch, different rings
+        with a.engine.mailbox(a.puzzle_id, a.pos, a.steps, a.reward, a.dgoals, a.terminated, a.truncated, a.flags, ring, 1000) as mb:
+            pending = []
+            for t in range(first, first + T // 2):
+                pending.append((t, mb.post(acts_dev[t])))  # (beyond `ring` posts ahead post() itself waits)
+                if len(pending) == ring:
+                    tt, seq = pending.pop(0)
+                    r, te, tr = mb.wait(seq)
+                    assert (r.view(np.uint64) == want[tt][0].view(np.uint64)).all() and (te == want[tt][1]).all() and (tr == want[tt][2]).all(), tt
+            for tt, seq in pending:
+                r, te, tr = mb.wait(seq)
+                assert (r.view(np.uint64) == want[tt][0].view(np.uint64)).all() and (te == want[tt][1]).all() and (tr == want[tt][2]).all(), tt
+    _same_state(a, b)
+
+
+def test_idle_limit_ends_the_kernel():
+    import torch
+
+    B = 512
+    a, b = _twins(B, 3, max_steps=50)
+    acts = np.random.default_rng(5).integers(0, 4, size=(4, B), dtype=np.uint8)
+    mb = a.mailbox(idle_ms=200)
+    mb.step(acts[0])
+    mb.step(acts[1])
+    time.sleep(0.45)
+    t0 = time.time()
+    torch.cuda.synchronize()  # the kernel has ended by itself: a device-wide synchronisation returns
+    assert time.time() - t0 < 1.0
+    with pytest.raises(RuntimeError):
+        mb.post(acts[2])
+    mb.close()
+    for t in range(2):
+        b.step(torch.as_tensor(acts[t]).to(b.device))
+    _same_state(a, b)  # the arrays hold the state after the last complete step
+    with a.mailbox() as mb2:  # a new one carries on
+        mb2.step(acts[2])
+    b.step(torch.as_tensor(acts[2]).to(b.device))
+    _same_state(a, b)
+
+
+def test_refusals():
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+    import bench
+
+    big = VecPushWorld([PushWorldPuzzle(p) for p in bench.level1_paths()[:2]], 64, observation=None, device=0)
+    big.reset()
+    with pytest.raises(ValueError):
+        big.mailbox()  # Level-1 puzzles do not fit 8 x 8 cells
+    a, _ = _twins(64, 2, max_steps=10)
+    with a.mailbox() as mb:
+        with pytest.raises(ValueError):
+            a.mailbox()
+        with pytest.raises(ValueError):
+            mb.post(np.zeros(63, np.uint8))
+        with pytest.raises(ValueError):
+            mb.wait(5)
