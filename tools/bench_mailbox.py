@@ -29,7 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--modes", default="0", help="PW_OPT_MAILBOX_MODE values to run, e.g. 0,1,2,4,6")
+    ap.add_argument("--modes", default="3", help="PW_OPT_MAILBOX_MODE values to run, e.g. 0,1,2,4,6")
     args = ap.parse_args()
     from pushworld_amd import benchmark_data as bd
     from pushworld_amd.puzzle import PushWorldPuzzle

@@ -266,6 +266,35 @@ def run_c2(cpu=True):
             vec.step(acts[k])
     dtg = wall(g.replay, 200, 5)
     out["hipgraph_64_single_step_launches"] = {"value": B * T / dtg, "unit": "env-steps/s", "us_per_step": 1e6 * dtg / T}
+    # the resident kernel (pw_mailbox_*): what a step costs a host that waits for its verdicts -- next to pw_step + synchronise
+    import time as _time
+
+    def sync_steps(n):
+        for k in range(n):
+            vec.step(acts[k % T])
+            torch.cuda.current_stream().synchronize()
+
+    sync_steps(50)
+    torch.cuda.synchronize()
+    t0 = _time.perf_counter()
+    sync_steps(1000)
+    us_launch_sync = (_time.perf_counter() - t0) / 1000 * 1e6
+    acts_run = acts.repeat(16, 1)[:1024].contiguous()
+    with vec.mailbox(ring=8) as mb:
+        mb.run(acts_run, 1)
+        us = {}
+        for name, ahead in (("sync", 1), ("ahead8", 8)):
+            best = None
+            for _ in range(3):
+                t0 = _time.perf_counter()
+                mb.run(acts_run, ahead)
+                d = (_time.perf_counter() - t0) / len(acts_run) * 1e6
+                best = d if best is None else min(best, d)
+            us[name] = best
+    out["mailbox_step"] = {"value": B / (us["sync"] * 1e-6), "unit": "env-steps/s", "us_per_step": us["sync"],
+                           "us_per_step_8_in_flight": us["ahead8"], "pw_step_plus_synchronise_us": us_launch_sync,
+                           "workload": "the same batch through pw_mailbox_run: every step posted by the host through a pinned word and "
+                                       "waited for (verdicts in pinned host memory); no launch, no stream synchronisation"}
     c = vec.counters()
     out["counters"] = c
     if cpu:
