@@ -452,8 +452,9 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
  * pw_step would have written, after every step -- and leaves the step's reward / terminated / truncated in pinned host memory,
  * which pw_mailbox_wait returns once the step is complete.  Up to `ring` steps may be posted ahead of the last complete one
  * (pw_mailbox_post waits beyond that); the pointers a wait returns stay valid until `ring` more steps have been posted.
- *   - sets whose puzzles all fit 8 x 8 cells with at most 8 movables (PW_OPT_STEP_BOARD_SET = 1: the Level-0 families), batches of
- *     up to 65 536 environments; PW_ELIMIT otherwise;
+ *   - any set, batches of up to 65 536 environments (every workgroup is resident): sets whose puzzles all fit 8 x 8 cells with at
+ *     most 8 movables (PW_OPT_STEP_BOARD_SET = 1: the Level-0 families of 5 x 5 puzzles) are stepped by the whole-grid boards pw_step
+ *     launches for them, the others one lane per environment over their overlap tables / row bitboards (pw_step_lane_kernel's step);
  *   - puzzle_id is read once, at the open: episodes restart (PW_STEP_AUTORESET) on the same puzzle;
  *   - everything queued on other streams for the arrays must be complete before the open, and while the mailbox is open the
  *     engine's other stepping calls fail (the environments live in the resident kernel); pw_counters is current after the close;
@@ -470,6 +471,11 @@ int pw_mailbox_open(PwEngine* e, const int32_t* puzzle_id, int8_t* pos, int32_t*
                     int32_t idle_ms /* 0 = 1000 */, PwMailbox** out);
 int pw_mailbox_post(PwMailbox* m, const uint8_t* actions, int32_t actions_on_host, uint64_t* seq /* out: 1, 2, ... */);
 int pw_mailbox_wait(PwMailbox* m, uint64_t seq, const double** reward, const uint8_t** terminated, const uint8_t** truncated);
+/* pw_mailbox_post + pw_mailbox_wait of that step in one call; pw_mailbox_layout: where the verdicts of step `seq` are --
+ * base + ((seq - 1) mod ring) * stride: reward float64 [B] at 0, terminated / truncated uint8 [B] at the two offsets. */
+int pw_mailbox_step(PwMailbox* m, const uint8_t* actions, int32_t actions_on_host, uint64_t* seq);
+int pw_mailbox_layout(PwMailbox* m, const uint8_t** base, int64_t* stride, int64_t* off_terminated, int64_t* off_truncated,
+                      int32_t* ring);
 /* num_steps posts from one uint8 [num_steps][B] array with at most `ahead` steps in flight (<= 1: every step waits for the one
  * before, the cadence of a host that chooses the next actions from a step's verdicts); returns when all are complete. */
 int pw_mailbox_run(PwMailbox* m, const uint8_t* actions, int32_t num_steps, int32_t actions_on_host, int32_t ahead,

@@ -121,6 +121,8 @@ SIGNATURES = {
     "pw_mailbox_wait": (c_int, [c_void_p, ctypes.c_uint64, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "pw_mailbox_run": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(ctypes.c_uint64)]),
     "pw_mailbox_close_profile": (c_int, [c_void_p, POINTER(c_int64)]),
+    "pw_mailbox_step": (c_int, [c_void_p, c_void_p, c_int32, POINTER(ctypes.c_uint64)]),
+    "pw_mailbox_layout": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
     "pw_mailbox_close": (c_int, [c_void_p]),
     "pw_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_step_render": (
@@ -457,7 +459,18 @@ class Mailbox:
                                   _ptr(terminated), _ptr(truncated), self.batch, flags, ring, idle_ms, ctypes.byref(handle)))
         self.handle = handle
         self._seq = ctypes.c_uint64()
+        self._seq_ref = ctypes.byref(self._seq)
         self._out = (c_void_p(), c_void_p(), c_void_p())
+        # numpy views of the pinned result slots, made once (a view per call costs more than the step)
+        base, stride, ot, ou, rg = c_void_p(), c_int64(), c_int64(), c_int64(), c_int32()
+        check(lib.pw_mailbox_layout(handle, ctypes.byref(base), ctypes.byref(stride), ctypes.byref(ot), ctypes.byref(ou), ctypes.byref(rg)))
+        self.ring = rg.value
+        B = self.batch
+        raw = np.ctypeslib.as_array(ctypes.cast(base, POINTER(ctypes.c_uint8)), (self.ring * stride.value,))
+        self._slots = []
+        for i in range(self.ring):
+            s = raw[i * stride.value:(i + 1) * stride.value]
+            self._slots.append((s[:8 * B].view(np.float64), s[ot.value:ot.value + B], s[ou.value:ou.value + B]))
 
     def post(self, actions) -> int:
         """``actions``: uint8 [B], a numpy array (host) or a tensor on the engine's device (complete: nothing is queued behind
@@ -478,15 +491,25 @@ class Mailbox:
     def wait(self, seq: int):
         if self.handle is None:
             raise RuntimeError("the mailbox is closed")
-        r, t, u = self._out
-        check(lib.pw_mailbox_wait(self.handle, seq, ctypes.byref(r), ctypes.byref(t), ctypes.byref(u)))
-        B = self.batch
-        return (np.ctypeslib.as_array(ctypes.cast(r, POINTER(ctypes.c_double)), (B,)),
-                np.ctypeslib.as_array(ctypes.cast(t, POINTER(ctypes.c_uint8)), (B,)),
-                np.ctypeslib.as_array(ctypes.cast(u, POINTER(ctypes.c_uint8)), (B,)))
+        check(lib.pw_mailbox_wait(self.handle, seq, None, None, None))
+        return self._slots[(seq - 1) % self.ring]
 
     def step(self, actions):
-        return self.wait(self.post(actions))
+        """``post`` + ``wait`` in one foreign call: ``(reward, terminated, truncated)`` of this step."""
+        if self.handle is None:
+            raise RuntimeError("the mailbox is closed")
+        if type(actions) is np.ndarray:
+            if actions.dtype != np.uint8 or actions.shape != (self.batch,) or not actions.flags.c_contiguous:
+                raise ValueError("actions must be a contiguous uint8 array of shape [num_envs]")
+            rc = lib.pw_mailbox_step(self.handle, actions.ctypes.data, 1, self._seq_ref)
+        else:
+            if actions.dtype != torch.uint8 or tuple(actions.shape) != (self.batch,) or not actions.is_contiguous() \
+                    or actions.device != self.engine.device:
+                raise ValueError("actions must be a contiguous uint8 tensor of shape [num_envs] on the engine's device")
+            rc = lib.pw_mailbox_step(self.handle, actions.data_ptr(), 0, self._seq_ref)
+        if rc:
+            check(rc)
+        return self._slots[(self._seq.value - 1) % self.ring]
 
     def run(self, actions, ahead: int = 1) -> int:
         """``pw_mailbox_run``: the steps of a uint8 [T, B] array (numpy: host, tensor: device) with at most ``ahead`` in flight;

@@ -282,8 +282,8 @@ class VecPushWorld:
         """Resident stepping (``pw_mailbox_open``) for hosts that need every step's verdicts before they choose the next actions:
         ``with vec.mailbox() as mb: reward, terminated, truncated = mb.step(actions)`` -- numpy views of pinned host memory, a
         few microseconds per step instead of a launch and a stream synchronisation.  Same semantics as ``step`` with
-        ``observation=None`` (this object's ``pos`` / ``steps`` / ``reward`` / ... tensors are kept up to date); only for sets of
-        puzzles that fit 8 x 8 cells, state only; ``step`` / ``rollout`` / ``reset`` of this object fail while it is open.  Bad
+        ``observation=None`` (this object's ``pos`` / ``steps`` / ``reward`` / ... tensors are kept up to date); state only, up to
+        65 536 environments; ``step`` / ``rollout`` / ``reset`` of this object fail while it is open.  Bad
         actions are flagged 0xFF in ``terminated`` / ``truncated`` and counted (``counters()['bad_actions']``) as in ``step``."""
         if not self._has_reset:
             raise RuntimeError("reset() must be called before step() can be called.")

@@ -149,15 +149,63 @@ def test_idle_limit_ends_the_kernel():
     _same_state(a, b)
 
 
-def test_refusals():
+@pytest.mark.parametrize("pool,B,tables", [("level1", 4096, True), ("level1", 1500, False), ("c4mix", 4096, True), ("level0_big", 3000, True)])
+def test_any_set_through_lane_step(pool, B, tables):
+    """Sets that do not fit 8 x 8 boards: the resident kernel steps them with lane_step (one lane per environment; overlap tables
+    where the engine has them for every puzzle, row bitboards otherwise) -- N_pad 16 (Level 1), 32 (the C4 mix with `Clean Sweep`),
+    8 (Level-0 puzzles beyond 8 x 8 cells) -- against pw_step on a twin, a third of the environments on their solution plans."""
+    import torch
+
+    import bench
+    from pushworld_amd import benchmark_data as bd
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.vec_env import VecPushWorld
-    import bench
+    from test_gpu_deep import _actions, _plan
 
-    big = VecPushWorld([PushWorldPuzzle(p) for p in bench.level1_paths()[:2]], 64, observation=None, device=0)
-    big.reset()
-    with pytest.raises(ValueError):
-        big.mailbox()  # Level-1 puzzles do not fit 8 x 8 cells
+    plans = {}
+    if pool == "level1":
+        paths = bench.level1_paths()
+        texts = [open(p).read() for p in paths]
+        plans = {i: _plan("level1", p) for i, p in enumerate(paths)}
+    elif pool == "c4mix":
+        texts = list(bd.level0_texts().values())[:40]
+        for lv in (1, 2, 3, 4):
+            for p in bd.level_paths(lv)[:12]:
+                plans[len(texts)] = _plan(f"level{lv}", p)
+                texts.append(open(p).read())
+        texts.append(open([p for p in bd.level_paths(2) if "Clean Sweep" in p][0]).read())
+    else:
+        texts = [t for t in bd.level0_texts().values() if len(t.strip().splitlines()) + 2 > 8][:30]
+        assert len(texts) == 30
+    T, max_steps = 120, 60
+    ids = (np.arange(B, dtype=np.int64) * len(texts)) // B
+    acts, _ = _actions(np.random.default_rng(B), ids, plans, T, 3)
+    acts[50, ::5] = 77
+    mk = lambda: VecPushWorld([PushWorldPuzzle(text=t) for t in texts], B, puzzle_ids=ids, max_steps=max_steps, observation=None,
+                              device=0, autoreset=True, engine_options=None if tables else {"step_tables": "none"})
+    a, b = mk(), mk()
+    assert a.engine.get_option("step_board_set") == 0
+    a.reset()
+    b.reset()
+    acts_dev = torch.as_tensor(acts).to(a.device)
+    torch.cuda.synchronize()
+    solved = 0
+    with a.mailbox() as mb:
+        for t in range(T):
+            r, te, tr = mb.step(acts[t] if t % 2 else acts_dev[t])
+            _, r2, te2, tr2 = b.step(acts_dev[t])
+            assert (r.view(np.uint64) == r2.cpu().numpy().view(np.uint64)).all(), t
+            assert (te == te2.cpu().numpy()).all() and (tr == tr2.cpu().numpy()).all(), t
+            solved += int((r == 10.0).sum())
+            if t % 30 == 29 or t == 50:
+                assert (a.pos.cpu() == b.pos.cpu()).all() and (a.steps.cpu() == b.steps.cpu()).all(), t
+    _same_state(a, b)
+    assert a.counters() == b.counters()
+    if plans:
+        assert solved > 0
+
+
+def test_refusals():
     a, _ = _twins(64, 2, max_steps=10)
     with a.mailbox() as mb:
         with pytest.raises(ValueError):
@@ -166,3 +214,5 @@ def test_refusals():
             mb.post(np.zeros(63, np.uint8))
         with pytest.raises(ValueError):
             mb.wait(5)
+        with pytest.raises(ValueError):
+            a.rollout(__import__("torch").zeros((2, 64), dtype=__import__("torch").uint8, device=a.device))

@@ -29,16 +29,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--pool", default="c2", help="c2 (one 5 x 5 Level-0 puzzle) or level1")
     ap.add_argument("--modes", default="3", help="PW_OPT_MAILBOX_MODE values to run, e.g. 0,1,2,4,6")
     args = ap.parse_args()
     from pushworld_amd import benchmark_data as bd
     from pushworld_amd.puzzle import PushWorldPuzzle
     from pushworld_amd.vec_env import VecPushWorld
 
-    member = "level0/base/train/level_0_base_train_0.pwp"
-    text = bd.level0_texts()[member] if member in bd.level0_texts() else next(iter(bd.level0_texts().values()))
     B, T = args.envs, args.steps
-    vec = VecPushWorld([PushWorldPuzzle(text=text)], B, max_steps=100, observation=None, device=0, autoreset=True)
+    if args.pool == "level1":  # the 68 Level-1 puzzles (N_pad 16: lane_step inside the resident kernel, lane groups for pw_step)
+        import bench
+        member = "level1 (68 puzzles, environments grouped by puzzle)"
+        puzzles = [PushWorldPuzzle(p) for p in bench.level1_paths()]
+        ids = (np.arange(B, dtype=np.int64) * len(puzzles)) // B
+        vec = VecPushWorld(puzzles, B, puzzle_ids=ids, max_steps=100, observation=None, device=0, autoreset=True)
+    else:
+        member = "level0/base/train/level_0_base_train_0.pwp"
+        text = bd.level0_texts()[member] if member in bd.level0_texts() else next(iter(bd.level0_texts().values()))
+        vec = VecPushWorld([PushWorldPuzzle(text=text)], B, max_steps=100, observation=None, device=0, autoreset=True)
     vec.reset()
     acts = np.random.default_rng(0).integers(0, 4, size=(T, B), dtype=np.uint8)
     acts_dev = torch.as_tensor(acts).to(vec.device)
