@@ -458,6 +458,8 @@ class Mailbox:
         check(lib.pw_mailbox_open(engine.handle, _ptr(puzzle_id), _ptr(pos), _ptr(steps), _ptr(reward), _ptr(dgoals),
                                   _ptr(terminated), _ptr(truncated), self.batch, flags, ring, idle_ms, ctypes.byref(handle)))
         self.handle = handle
+        import weakref
+        engine._mailbox = weakref.ref(self)
         self._seq = ctypes.c_uint64()
         self._seq_ref = ctypes.byref(self._seq)
         self._out = (c_void_p(), c_void_p(), c_void_p())
@@ -473,8 +475,8 @@ class Mailbox:
             self._slots.append((s[:8 * B].view(np.float64), s[ot.value:ot.value + B], s[ou.value:ou.value + B]))
 
     def post(self, actions) -> int:
-        """``actions``: uint8 [B], a numpy array (host) or a tensor on the engine's device (complete: nothing is queued behind
-        a stream here)."""
+        """``actions``: uint8 [B], a numpy array (host) or a tensor on the engine's device (torch's current stream is
+        synchronised first: the resident kernel is not in any stream's order)."""
         if self.handle is None:
             raise RuntimeError("the mailbox is closed")
         if isinstance(actions, np.ndarray):
@@ -485,6 +487,7 @@ class Mailbox:
             if actions.dtype != torch.uint8 or tuple(actions.shape) != (self.batch,) or not actions.is_contiguous() \
                     or actions.device != self.engine.device:
                 raise ValueError("actions must be a contiguous uint8 tensor of shape [num_envs] on the engine's device")
+            torch.cuda.current_stream(self.engine.device).synchronize()  # (the kernel that produced them has finished)
             check(lib.pw_mailbox_post(self.handle, _ptr(actions), 0, ctypes.byref(self._seq)))
         return self._seq.value
 
@@ -506,6 +509,7 @@ class Mailbox:
             if actions.dtype != torch.uint8 or tuple(actions.shape) != (self.batch,) or not actions.is_contiguous() \
                     or actions.device != self.engine.device:
                 raise ValueError("actions must be a contiguous uint8 tensor of shape [num_envs] on the engine's device")
+            torch.cuda.current_stream(self.engine.device).synchronize()  # (the kernel that produced them has finished)
             rc = lib.pw_mailbox_step(self.handle, actions.data_ptr(), 0, self._seq_ref)
         if rc:
             check(rc)
@@ -911,5 +915,9 @@ class Engine:
     def __del__(self):
         h = getattr(self, "handle", None)
         if h and lib is not None:
+            mb = getattr(self, "_mailbox", None)
+            mb = mb() if mb is not None else None
+            if mb is not None:
+                mb.handle = None  # (pw_engine_destroy closes an open mailbox itself)
             lib.pw_engine_destroy(h)
             self.handle = None
