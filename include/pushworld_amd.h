@@ -252,7 +252,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       (16-lane groups for every environment) */
 #define PW_OPT_STEP_BLOCK_ORDER 20   /* lane-group step kernels: 0 workgroups take the environments in index order, 1 in reverse --
                                       for batches sorted by puzzle whose expensive puzzles (many / big movables) come last:
-                                      they then start first and the cheap ones fill the tail of the launch */
+                                      they then start first and the cheap ones fill the tail of the launch; + 2: a contiguous eighth of
+                                      the blocks per XCD (A/B runs; measured slower: profiles/r05_step_block_order.txt) */
 #define PW_OPT_STEP_LANE_BATCH 21    /* state-only launches (pw_step, pw_rollout) of at least this many environments run ONE LANE per
                                       environment (the table-only formulation, 64 environments per wavefront: ~3x fewer
                                       instructions per environment than a lane group, but an eighth of the wavefronts -- it wins
@@ -464,7 +465,9 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
  *     otherwise hold every device-wide synchronisation (hipDeviceSynchronize, torch.cuda.synchronize) for ever.  pw_mailbox_post
  *     fails with PW_EDEVICE once more than idle_ms / 2 have passed since the previous post (the mailbox has expired: close it
  *     and open a new one; the arrays hold the state after the last complete step).
- * Measured (C2, 4 096 environments, tools/bench_mailbox.py): see DESIGN.md K1f. */
+ *   - one host thread at a time per mailbox (post / wait / step / run / close are not synchronised against each other).
+ * Measured (C2, 4 096 environments, tools/bench_mailbox.py, profiles/r05_mailbox.json): 6.1 us per synchronous step against 17.8 us
+ * for pw_step + a stream synchronisation; 3.6 us with 8 steps in flight.  DESIGN.md K1f. */
 typedef struct PwMailbox PwMailbox;
 int pw_mailbox_open(PwEngine* e, const int32_t* puzzle_id, int8_t* pos, int32_t* steps, double* reward, int8_t* dgoals,
                     uint8_t* terminated, uint8_t* truncated, int32_t batch, uint32_t flags, int32_t ring /* 0 = 8 */,

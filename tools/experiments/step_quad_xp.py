@@ -93,11 +93,12 @@ def main():
         vec = build(kind, args.envs)
         print(kind, "N_pad", vec.num_objects_padded, "puzzles", vec.num_puzzles, "with a 16 x 16 record", vec.engine.get_option("step_quad16_puzzles"), flush=True)
         for mode in args.modes.split(","):
-            quad, kern = mode.split(":")
+            quad, kern, *rest = mode.split(":")
+            vec.engine.set_option("step_block_order", int(rest[0]) if rest else 0)
             lanes = kern == "lanes"
             vec.engine.set_option("step_quad16", quad)
             vec.engine.set_option("step_lane_batch", 1 if lanes else 2**31)
-            measure(vec, f"{kind} quad16={quad} {'lanes' if lanes else 'groups'}")
+            measure(vec, f"{kind} quad16={quad} {'lanes' if lanes else 'groups'} order={rest[0] if rest else 0}")
         del vec
         torch.cuda.empty_cache()
 
