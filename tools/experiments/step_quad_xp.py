@@ -38,6 +38,10 @@ def build(kind, B=65536):
     rng = np.random.default_rng(100)
     if kind == "l0":
         ids = np.sort(rng.integers(0, len(l0), size=B))
+    elif kind.startswith("hi") and len(kind) > 2:  # "hi8": only every (223 / 8)-th Level 1-4 puzzle -- a small table working set
+        k = int(kind[2:])
+        pick = np.arange(0, len(hi), max(1, len(hi) // k))[:k]
+        ids = np.sort(len(l0) + pick[rng.integers(0, len(pick), size=B)])
     else:
         ids = np.sort(len(l0) + rng.integers(0, len(hi), size=B))
     return VecPushWorld(pset, B, puzzle_ids=ids, max_steps=200, observation=None, autoreset=True)
