@@ -124,6 +124,32 @@ def test_posts_ahead_of_the_waits_and_reopen():
     _same_state(a, b)
 
 
+@pytest.mark.parametrize("ring,ahead,host", [(2, 2, False), (2, 1, True), (4, 4, True), (8, 8, False), (64, 64, False)])
+def test_soak_slots_come_round(ring, ahead, host):
+    """30 000 steps through pw_mailbox_run with every slot of the ring (the host's words, the relay words, the arrival counters,
+    the result slots) reused thousands of times at the shortest distance the protocol allows: the final state, the counters and the
+    verdicts of the last step equal those of pw_rollout over the same actions on a twin."""
+    import torch
+
+    B, T = 4096, 30000
+    a, b = _twins(B, 11, max_steps=40)
+    acts = np.random.default_rng(ring * 100 + ahead).integers(0, 4, size=(T, B), dtype=np.uint8)
+    acts_dev = torch.as_tensor(acts).to(a.device)
+    torch.cuda.synchronize()
+    for k in range(0, T, 1000):
+        b.rollout(acts_dev[k:k + 1000])
+    mb = a.engine.mailbox(a.puzzle_id, a.pos, a.steps, a.reward, a.dgoals, a.terminated, a.truncated, a.flags, ring, 2000)
+    last = mb.run(acts if host else acts_dev, ahead)
+    assert last == T
+    r, te, tr = mb.wait(last)
+    assert (r.view(np.uint64) == b.reward.cpu().numpy().view(np.uint64)).all()
+    assert (te == b.terminated.cpu().numpy()).all() and (tr == b.truncated.cpu().numpy()).all()
+    prof = mb.close(profile=True)
+    assert prof["steps"] == T and prof["ended_by"] == "stop"
+    _same_state(a, b)
+    assert a.counters() == b.counters()
+
+
 def test_idle_limit_ends_the_kernel():
     import torch
 

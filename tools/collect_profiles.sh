@@ -18,12 +18,6 @@ SQ2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD 
 summ() { python tools/rocprof_summary.py "$1" 2>&1 | grep -v "at::\|rocclr\|hipMem\|Cijk\|__amd"; }
 stale() { [ -n "$ALL" ] && { echo "$*"; return; }; python tools/prof_state.py stale "$@"; }
 
-# ---- always: the bench line of this code and the kernel trace of the same command
-$T python bench.py --steps 20 --warmup 5 > $P/bench.json 2> $P/bench.err
-cp gpurun_out/bench_full.json $P/bench_full.json 2>/dev/null
-$T rocprofv3 --kernel-trace --stats -d $P -o trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs > $P/trace_bench_line.json 2> $P/trace.log
-summ $P/trace_results.db > $P/trace_summary.txt
-
 # ---- the headline render kernel's counters: only when pw_render_kernels.inc changed
 RSTALE=$(python - <<'PY'
 import json, sys
@@ -107,5 +101,20 @@ if [ -n "$ALL" ] || ! grep -q "$SSHA" profiles/${TAG}_search_big_trace.txt 2>/de
   $T rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P -o search_big_write -- python tools/bench_search.py > /dev/null 2> $P/search_big_write.log
   for f in trace fetch write; do { echo "# pw_search.inc sha256 $SSHA"; summ $P/search_big_${f}_results.db; } > $P/search_big_${f}_summary.txt; done
 fi
+# ---- always, and LAST: the bench line of this code and the kernel trace of the same command -- after the records above, so that
+# the line's measured-traffic fields (hbm_frac, traffic_ratio) come from records of THIS code (bench.py reads them from profiles/)
+python - <<PY
+import json, shutil
+for name in ("pmc_kernels_latest.json", "pmc_render_latest.json"):
+    try:
+        json.load(open("$P/" + name))
+        shutil.copy("$P/" + name, "profiles/" + name)
+    except Exception:
+        pass
+PY
+$T python bench.py --steps 20 --warmup 5 > $P/bench.json 2> $P/bench.err
+cp gpurun_out/bench_full.json $P/bench_full.json 2>/dev/null
+$T rocprofv3 --kernel-trace --stats -d $P -o trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs > $P/trace_bench_line.json 2> $P/trace.log
+summ $P/trace_results.db > $P/trace_summary.txt
 rm -f $P/*.db
 tail -1 $P/bench.json | cut -c1-400
