@@ -330,8 +330,8 @@ int pw_engine_tune_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* p
  *   pw_obs_alloc        one buffer.
  *   pw_obs_alloc_tuned  allocates up to max_candidates buffers (all alive at once, so that each lands on other physical
  *                       memory), takes a quick look at each (the best of five launch configurations, three launches
- *                       each), keeps the first that is of the fast class (PW_OPT_OBS_ACCEPT_GBS, or 8 % faster than the
- *                       slowest seen) or else the fastest, RELEASES THE OTHERS TO THE DEVICE and runs
+ *                       each), keeps the first that is of the fast class (PW_OPT_OBS_ACCEPT_GBS; from the 16th
+ *                       candidate on also one 8 % faster than the slowest seen) or else the fastest, RELEASES THE OTHERS TO THE DEVICE and runs
  *                       pw_engine_tune_render on the kept one.  It holds the observations of (puzzle_id, pos), the
  *                       engine its tuned launch configuration; returns the tuner's index (>= 0).  candidate_ms (host
  *                       float [max_candidates], may be NULL) receives every candidate's screened time, *tried how many
