@@ -354,6 +354,8 @@ struct PageRec {
 };
 
 #include "pw_step_kernels.inc"
+#include "pw_mailbox_kernels.inc"
+#include "pw_expand_kernels.inc"
 #include "pw_render_kernels.inc"
 #include "pw_engine.inc"
 #include "pw_mailbox.inc"
