@@ -467,7 +467,7 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
  *     and open a new one; the arrays hold the state after the last complete step).
  *   - one host thread at a time per mailbox (post / wait / step / run / close are not synchronised against each other).
  * Measured (C2, 4 096 environments, tools/bench_mailbox.py, profiles/r05_mailbox.json): 6.1 us per synchronous step against 17.8 us
- * for pw_step + a stream synchronisation; 3.6 us with 8 steps in flight.  DESIGN.md K1f. */
+ * for pw_step + a stream synchronisation; 3.2 us with 8 steps in flight.  DESIGN.md K1f. */
 typedef struct PwMailbox PwMailbox;
 int pw_mailbox_open(PwEngine* e, const int32_t* puzzle_id, int8_t* pos, int32_t* steps, double* reward, int8_t* dgoals,
                     uint8_t* terminated, uint8_t* truncated, int32_t batch, uint32_t flags, int32_t ring /* 0 = 8 */,
