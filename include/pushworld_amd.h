@@ -507,11 +507,19 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
  * including every byte of `obs`, equals what pw_step_render produces -- but only the pixel rows swept
  * by the objects that moved are written (none for a blocked move; the whole image for environments
  * reset by PW_STEP_AUTORESET, which also covers a puzzle_id changed by pw_resample).  uint8 /
- * pixels_per_cell 3 engines; any other engine silently takes the pw_step_render path. */
+ * pixels_per_cell 3 engines; any other engine silently takes the pw_step_render path.
+ * Returns PW_OK, or 1 when the launch will also write the engine's completion word (below). */
 int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
                          int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
                          uint8_t* truncated, void* obs, int64_t env_stride_bytes, int32_t batch,
                          uint32_t flags, void* stream);
+
+/* A completion word for the single-environment adapters (gym / dm_env: batch 1, observation and state in pinned host memory):
+ * `word` = 8 bytes of pinned, device-addressable host memory (NULL switches it off; the count restarts at 0).  A
+ * pw_step_render_delta on a batch of ONE that redraws with the generic kernel (every engine but uint8 / pixels_per_cell 3) then
+ * returns 1 instead of PW_OK and its last kernel writes k -- the number of such calls since this call -- into the word after
+ * everything else it wrote: the host polls the word instead of synchronising the stream (~8 us of runtime per step here). */
+int pw_engine_set_step_signal(PwEngine* e, void* word);
 
 /* Planner successor expansion, best_first_search.h:76-78 calling
  * PushWorldPuzzle::getNextState (pushworld_puzzle.cc:386-460) and satisfiesGoal (:462-469)

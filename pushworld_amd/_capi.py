@@ -124,6 +124,7 @@ SIGNATURES = {
     "pw_mailbox_step": (c_int, [c_void_p, c_void_p, c_int32, POINTER(ctypes.c_uint64)]),
     "pw_mailbox_layout": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
     "pw_mailbox_close": (c_int, [c_void_p]),
+    "pw_engine_set_step_signal": (c_int, [c_void_p, c_void_p]),
     "pw_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_step_render": (
         c_int,
@@ -760,9 +761,15 @@ class Engine:
 
         def call(actions_ptr, _keep=keep):
             rc = fn(h, a[0], actions_ptr, a[1], a[2], a[3], a[4], a[5], a[6], a[7], stride, batch, flags, _raw_stream(dev))
-            if rc:
+            if rc < 0:
                 check(rc)
+            return rc  # (1: the engine's completion word will be written -- pw_engine_set_step_signal)
         return call
+
+    def set_step_signal(self, word) -> None:
+        """``pw_engine_set_step_signal``: ``word`` = a pinned int64 / uint64 tensor of one element, or None."""
+        check(lib.pw_engine_set_step_signal(self.handle, None if word is None else c_void_p(word.data_ptr())))
+        self._step_signal_keep = word
 
     def next_state(self, puzzle_index: int, xy_in, action: int, xy_out, info=None) -> None:
         """``pw_next_state``: host buffers in / out (bytes-like of 2 N int8 each), one launch, no copy command."""

@@ -66,11 +66,13 @@ class SingleEnvCore:
         self._engine = _capi.Engine(self._pset, max_steps, pixels_per_cell, border_width, _capi.OBS_F32,
                                     self._max_cell_height, self._max_cell_width)
         self._render_engines = {}
-        # all per-step scalars and the positions live in ONE small device buffer (typed views into it), and
-        # come back to the host together with the observation in a single stream synchronisation per step
+        # all per-step scalars and the positions live in ONE small buffer (typed views into it) in pinned HOST memory, which the
+        # device addresses too: the step kernel reads and writes it over PCIe, and the host reads it after the one stream
+        # synchronisation of a step -- no copy command (a device buffer + an 80-byte hipMemcpyAsync before: the copy engine's
+        # latency was a third of the step, 18.5 k -> 22.8 k gym steps/s on a Level-1 puzzle; tools/experiments/c1_hostobs_xp.py)
         dev_t = self._engine.device
         npad = self._engine.np
-        self._raw = torch.zeros((16 + 2 * npad,), dtype=torch.uint8, device=dev_t)
+        self._raw = torch.zeros((16 + 2 * npad,), dtype=torch.uint8).pin_memory()
         self._buf = {
             "reward": self._raw[0:8].view(torch.float64),
             "steps": self._raw[8:12].view(torch.int32),
@@ -86,20 +88,34 @@ class SingleEnvCore:
         # (9.7 k -> 18 k gym steps/s on the C1 puzzle at max_steps 50; a device buffer + hipMemcpy of the whole frame before)
         self._obs_storage, self._obs = self._engine.alloc_obs_host(1)
         self.obs_shape = self._engine.obs_shape
-        self._raw_host = torch.zeros_like(self._raw, device="cpu").pin_memory()
+        self._raw_np = self._raw.numpy()
         # the step's pointers never change: marshalled once (the action is a byte of self._acts)
         b = self._buf
         self._step_call = self._engine.bind_step_render(self._pid, b["pos"], b["steps"], b["reward"], b["dgoals"], b["terminated"],
                                                         b["truncated"], self._obs_storage, 0, delta=True)
         self._acts_ptr = self._acts.data_ptr()
+        # ... and the last kernel of a step says when everything is written: the host polls this word instead of synchronising
+        # the stream (the runtime's synchronisation costs ~8 us a step)
+        self._signal = torch.zeros((1,), dtype=torch.int64).pin_memory()
+        self._signal_np = self._signal.numpy()
+        self._signalled = 0
+        self._engine.set_step_signal(self._signal)
         self._stream = torch.cuda.current_stream(dev_t)
 
     # ------------------------------------------------------------------
-    def _read_back(self):
-        """Scalars + positions to pinned host memory (one async copy), one synchronisation; the observation is there already."""
-        self._raw_host.copy_(self._raw, non_blocking=True)
-        torch.cuda.current_stream(self._engine.device).synchronize()
-        return self._obs[0].numpy().copy(), self._raw_host.numpy()
+    def _read_back(self, signalled: bool = False):
+        """The observation, the scalars and the positions are in pinned host memory already: wait for the step's completion word
+        (or, without one, synchronise the stream)."""
+        if signalled:
+            word, want = self._signal_np, self._signalled
+            for _ in range(200000):  # (~20 ms: then ask the runtime -- a failed launch must not spin for ever)
+                if word[0] == want:
+                    break
+            else:
+                torch.cuda.current_stream(self._engine.device).synchronize()
+        else:
+            torch.cuda.current_stream(self._engine.device).synchronize()
+        return self._obs[0].numpy().copy(), self._raw_np
 
     def core_reset(self, seed: Optional[int]) -> np.ndarray:
         if seed is not None:
@@ -123,8 +139,10 @@ class SingleEnvCore:
         if not 0 <= action <= 3:  # (the adapters have checked their action spaces; the pointer arithmetic below must not run wild)
             raise ValueError("The provided action is not in the action space.")
         # the observation buffer is this environment's own and always current: incremental redraw (pw_step_render_delta)
-        self._step_call(self._acts_ptr + action)
-        observation, raw = self._read_back()
+        signalled = self._step_call(self._acts_ptr + action) == 1
+        if signalled:
+            self._signalled += 1
+        observation, raw = self._read_back(signalled)
         self._steps += 1
         n = self._current_puzzle.num_movables
         xy = raw[16:16 + 2 * n].view(np.int8)

@@ -183,6 +183,8 @@ struct PwEngine {
   std::mutex lat_mu;       // pw_next_state / pw_plan_states share lat_host and lat_seq: one call at a time per engine
   PwMailbox* mailbox;     // the open resident step kernel of this engine (pw_mailbox_open), or NULL
   int mailbox_mode;       // PW_OPT_MAILBOX_MODE
+  unsigned long long* step_signal;     // pw_engine_set_step_signal: completion word of pw_step_render_delta on a batch of one
+  unsigned long long step_signal_seq;  // ... and the last number written to it
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)
   int64_t dirty_cap;
   uint8_t* d_simg;         // per puzzle: observation of the static layers only (page-ordered and delta kernels)

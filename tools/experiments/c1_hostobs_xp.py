@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Round-4 experiment, AS RUN at commit e7ae6e8 (before the product adopted its result -- pushworld_amd/_single_env.py now keeps
+"""(HISTORICAL: written against the round-4 adapter, whose scalars lived in a device buffer; since round 5 the product IS
+variant 2 below and `_raw_host` no longer exists -- kept for the record of what was measured.)
+Round-4 experiment, AS RUN at commit e7ae6e8 (before the product adopted its result -- pushworld_amd/_single_env.py now keeps
 the observation in pinned host memory itself, so "device buffer + copy" below no longer is what `PushWorldEnv` does): the
 single-environment adapters with the observation buffer in pinned HOST memory (the render kernels write it over PCIe, no
 copy command) against the device buffer + hipMemcpy: 9.7 k -> 18.1 k steps/s at max_steps 50; the state there too: 18.2 k."""
