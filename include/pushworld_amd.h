@@ -517,7 +517,7 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
 /* A completion word for the single-environment adapters (gym / dm_env: batch 1, observation and state in pinned host memory):
  * `word` = 8 bytes of pinned, device-addressable host memory (NULL switches it off; the count restarts at 0).  A
  * pw_step_render_delta on a batch of ONE that redraws with the generic kernel (every engine but uint8 / pixels_per_cell 3) then
- * returns 1 instead of PW_OK and its last kernel writes k -- the number of such calls since this call -- into the word after
+ * returns 1 instead of PW_OK and the last workgroup of its last kernel writes k -- the number of such calls since this call -- into the word after
  * everything else it wrote: the host polls the word instead of synchronising the stream (~8 us of runtime per step here). */
 int pw_engine_set_step_signal(PwEngine* e, void* word);
 
