@@ -89,6 +89,7 @@ class SingleEnvCore:
         self._obs_storage, self._obs = self._engine.alloc_obs_host(1)
         self.obs_shape = self._engine.obs_shape
         self._raw_np = self._raw.numpy()
+        self._obs_np = self._obs[0].numpy()  # (a view: made once, copied per step)
         # the step's pointers never change: marshalled once (the action is a byte of self._acts)
         b = self._buf
         self._step_call = self._engine.bind_step_render(self._pid, b["pos"], b["steps"], b["reward"], b["dgoals"], b["terminated"],
@@ -115,7 +116,7 @@ class SingleEnvCore:
                 torch.cuda.current_stream(self._engine.device).synchronize()
         else:
             torch.cuda.current_stream(self._engine.device).synchronize()
-        return self._obs[0].numpy().copy(), self._raw_np
+        return self._obs_np.copy(), self._raw_np
 
     def core_reset(self, seed: Optional[int]) -> np.ndarray:
         if seed is not None:
