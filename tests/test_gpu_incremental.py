@@ -175,3 +175,49 @@ def test_incremental_full_size_is_a_pure_function_of_the_state():
         assert torch.equal(got, vec._obs_storage)
         del vec, got
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kw", [dict(observation="float32", pixels_per_cell=20, border_width=2),   # the gym default: 8 workgroups
+                                dict(observation="uint8", pixels_per_cell=8, border_width=2),      # a small frame: one workgroup
+                                dict(observation="float32", pixels_per_cell=5, border_width=1)])
+def test_batch_of_one_completion_word_and_split_redraw(golden, kw):
+    """pw_step_render_delta on a batch of ONE (what the gym / dm_env adapters launch): the changed rows leave through eight
+    workgroups where the frame has >= 64 KB, the call returns 1 and the last workgroup writes the call's number into the engine's
+    completion word (pw_engine_set_step_signal) after everything else -- polled here WITHOUT a stream synchronisation; the buffer
+    equals the full render's every step, through autoresets (whole-frame redraws) and blocked moves (nothing to redraw)."""
+    import time
+
+    import torch
+    from pushworld_amd.vec_env import VecPushWorld
+
+    keys = [k for k in golden.keys if k.startswith("bench:level1/")][:3]
+    for key in keys:
+        pool = _pool(golden, [key])
+        common = dict(max_steps=14, autoreset=True, **kw)
+        full = VecPushWorld(pool, 1, **common)
+        inc = VecPushWorld(pool, 1, incremental=True, **common)
+        word = torch.zeros((1,), dtype=torch.int64).pin_memory()
+        inc.engine.set_step_signal(word)
+        assert torch.equal(full.reset(), inc.reset())
+        torch.cuda.synchronize()
+        g = torch.Generator(device=full.device).manual_seed(4)
+        signalled = 0
+        for t in range(60):
+            a = torch.randint(0, 4, (1,), dtype=torch.uint8, device=full.device, generator=g)
+            torch.cuda.synchronize()  # (the action is there; nothing below waits for the stream)
+            rc = inc._call_step_delta(a.data_ptr())
+            assert rc == 1, (key, t)  # the generic kernel redraws: the word will be written
+            signalled += 1
+            t0 = time.time()
+            while int(word[0]) != signalled:
+                assert time.time() - t0 < 5.0, (key, t, int(word[0]))
+            got = inc._obs_storage.clone()  # (queued behind the kernels that have already reported)
+            fo = full.step(a)
+            assert torch.equal(full._obs_storage, got), (key, t)
+            assert torch.equal(full.pos, inc.pos) and torch.equal(fo[1], inc.reward) and torch.equal(fo[2], inc.terminated), (key, t)
+        inc.engine.set_step_signal(None)
+        a = torch.zeros((1,), dtype=torch.uint8, device=full.device)
+        assert inc._call_step_delta(a.data_ptr()) == 0  # switched off: PW_OK, no word
+        full.step(a)
+        torch.cuda.synchronize()
+        assert torch.equal(full._obs_storage, inc._obs_storage) and int(word[0]) == signalled
