@@ -279,7 +279,9 @@ def main():
     from pushworld_amd.sharding import pin_to_device_numa
     numa_node, affinity_before = (None, None) if args.no_numa_pin else pin_to_device_numa(device_index)
 
+    t_ctor = time.perf_counter()
     wl = build_workload(args, rank, world, device_index)
+    constructor_s = time.perf_counter() - t_ctor  # parse + pack + tables + (observation runs) the allocator screen and the tuner
     vec = wl["vec"]
     eng = vec.engine
     dev = vec.device
@@ -375,11 +377,11 @@ def main():
         own_gbs = B * eng.obs_bytes / (tuned_ms * 1e-3) / 1e9 if tuned_ms > 0 else 0.0
         rank_row = [float(own_ms.mean()), float(np.median(own_ms)), float(own_ms.min()), tuned_ms,
                     float(len(vec.tuned_candidates_ms)), 1.0 if own_gbs >= eng.get_option("obs_accept_gbs") else 0.0,
-                    -1.0 if numa_node is None else float(numa_node)]
+                    -1.0 if numa_node is None else float(numa_node), float(eng.get_option("obs_screen_ms")) * 1e-3, constructor_s]
     else:
         own_ms = np.array([a.elapsed_time(b) for a, b in step_events], dtype=np.float64)
         rank_row = [float(own_ms.mean()), float(np.median(own_ms)), float(own_ms.min()), 0.0, 0.0, 0.0,
-                    -1.0 if numa_node is None else float(numa_node)]
+                    -1.0 if numa_node is None else float(numa_node), 0.0, constructor_s]
     rank_rows = gather_vectors(rank_row, device=red_dev)
     elapsed = float(np.median(win_max))
     total_steps = counters["env_steps"] // M  # per window, all ranks (device-counted)
@@ -433,6 +435,11 @@ def main():
             # reset: same bytes, the fastest of 16 page orders / occupancies for THIS observation buffer)
             "render_launch": {"tuned_index": vec.tuned_config, "tuned_ms": vec.tuned_ms,
                               "allocations_tried": len(vec.tuned_candidates_ms),
+                              # wall clock of VecPushWorld(...) on rank 0 and, inside it, of the allocator's candidate screen
+                              # (bounded by PW_OPT_OBS_TUNE_MS); every rank's pair is in per_rank
+                              "constructor_s": round(constructor_s, 3),
+                              "screen_s": round(eng.get_option("obs_screen_ms") * 1e-3, 3),
+                              "screen_budget_s": round(eng.get_option("obs_tune_ms") * 1e-3, 3),
                               "allocations_max": args.tune_allocations if args.tune_allocations is not None else "product default (<= 32, within a third of the device memory)",
                               "allocator": ("pw_obs_alloc_tuned (HIP virtual-memory chunks; losers released to the device)"
                                             if getattr(vec, "obs_owned_by_library", False) else "torch (caller-owned buffer, tuned in place)"),
@@ -467,7 +474,7 @@ def main():
         # render launch: observation write + positions and puzzle id read
         algo = B * (eng.obs_bytes + 2 * n_obj + 4)
         achieved = algo / render_s / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_from = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_render_latest.json")
         if os.path.exists(pmc):
             try:
@@ -480,6 +487,7 @@ def main():
                     variant = rec.get("by_page_load_all", {}).get(str(eng.get_option("page_load_all")))
                     if rec.get("kernel_source_sha16") == kernel_source_sha() and variant:
                         traffic = variant.get("hbm_bytes_per_launch")
+                        traffic_from = "recorded:" + str(rec.get("kernel_source_sha16"))
                         traffic_source = "recorded: profiles/pmc_render_latest.json (rocprofv3 --pmc passes of " \
                                          + str(rec.get("source", "an earlier run")) + ", head " + str(rec.get("git_head")) \
                                          + ", same kernel source), not measured in this run"
@@ -504,6 +512,9 @@ def main():
             "traffic_ratio": (traffic / algo) if traffic else None,
             "traffic": traffic,
             "traffic_source": traffic_source,
+            # where `traffic` comes from, in a word: "recorded:<sha16 of the kernel source the PMC passes ran on>" -- a number of
+            # profiles/, not of this run (the PMC passes need rocprofv3 around the process)
+            "traffic_from": traffic_from,
             "algorithmic_bytes_per_launch": algo,
             "avg_launch_ms": float(ms.mean()),
             "median_launch_ms": float(np.median(ms)),
@@ -516,7 +527,9 @@ def main():
             "per_rank_frac": [algo / (r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS for r in rank_rows],
         }
         out["config"]["render_launch"]["per_rank"] = [
-            {"tuned_ms": round(r[3], 4), "allocations_tried": int(r[4]), "fast_class": bool(r[5])} for r in rank_rows]
+            {"tuned_ms": round(r[3], 4), "allocations_tried": int(r[4]), "fast_class": bool(r[5]), "screen_s": round(r[7], 3),
+             "constructor_s": round(r[8], 3)} for r in rank_rows]
+        out["config"]["render_launch"]["fast_class"] = bool(rank_rows[0][5])
         slow = [i for i, r in enumerate(rank_rows) if not r[5]]
         if slow:
             out["config"]["render_launch"]["ranks_without_a_fast_buffer"] = slow

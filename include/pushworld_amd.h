@@ -304,6 +304,25 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       memory, 3 (default) a workgroup of its own that does nothing else and runs ahead of the stepping
                                       ones; bit 2 (+4): system-scope fences around a step instead of system-scope accesses.  Same results
                                       (C2 round trip 38 / 10.8 / 6.2 / 6.0 us: profiles/r05_mailbox.json). */
+#define PW_OPT_BIND_MIN_ENVS 36      /* pw_batch_bind: a puzzle is bound when at least this many environments of the batch play it (0 = default 48) */
+#define PW_OPT_BIND_FUSED 37         /* launches of a partly bound batch: 0 (default) single steps run segments and lane groups in ONE launch (where the
+                                      per-workgroup lane-group kernel applies), launches of several steps as two kernels side by side on two
+                                      streams (joined by events on the caller's stream); 2 two launches one after the other on the caller's
+                                      stream (A/B runs) */
+#define PW_OPT_BIND_PUZZLES 38       /* read-only: puzzles of the set that can be bound (their table block fits 16 KB of LDS) */
+#define PW_OPT_BIND_MISMATCHES 39    /* read-only (synchronises the device): environments that bound launches found with a puzzle id other than
+                                      the one they were bound to, since the engine was created -- 0 unless the caller changed puzzle_id
+                                      behind the binding's back */
+#define PW_OPT_BIND_LANES 42         /* pw_batch_bind (read when binding): lanes per environment of the segments -- 0 automatic (1 up to 7 movables, 2 from 8,
+                                      4 from 12: a step's latency grows with the movables and a launch lasts as long as its slowest segment),
+                                      1 / 2 / 3 = at most 1 / 2 / 4 (A/B runs) */
+#define PW_OPT_BIND_ROLLOUTS 43      /* launches of several steps (pw_rollout) on a bound batch: 0 (default) the segments when EVERY environment of the batch
+                                      is bound, else the lane groups for all of them (measured: next to lane groups that fill the chip the
+                                      segment role does not finish sooner); 1 always (segments and lane groups side by side on two streams), 2 never */
+#define PW_OPT_OBS_TUNE_MS 40        /* pw_obs_alloc_tuned: wall-clock budget of the candidate screen in milliseconds (0 = default 10 000): no
+                                      further candidate is allocated once it is spent (the best so far is kept and tuned) -- bounds the
+                                      constructor when several ranks of a node screen at the same time */
+#define PW_OPT_OBS_SCREEN_MS 41      /* read-only: milliseconds the last pw_obs_alloc_tuned spent allocating, screening and releasing candidates */
 int pw_engine_set_option(PwEngine* e, int32_t option, int64_t value);
 int64_t pw_engine_get_option(const PwEngine* e, int32_t option);
 /* Durations (milliseconds) of the render launches recorded since the last call, in launch order
@@ -331,7 +350,8 @@ int pw_engine_tune_render(PwEngine* e, const int32_t* puzzle_id, const int8_t* p
  *   pw_obs_alloc_tuned  allocates up to max_candidates buffers (all alive at once, so that each lands on other physical
  *                       memory), takes a quick look at each (the best of five launch configurations, three launches
  *                       each), keeps the first that is of the fast class (PW_OPT_OBS_ACCEPT_GBS; from the 16th
- *                       candidate on also one 8 % faster than the slowest seen) or else the fastest, RELEASES THE OTHERS TO THE DEVICE and runs
+ *                       candidate on also one 8 % faster than the slowest seen; no further candidate once PW_OPT_OBS_TUNE_MS of wall
+ *                       clock are spent) or else the fastest, RELEASES THE OTHERS TO THE DEVICE and runs
  *                       pw_engine_tune_render on the kept one.  It holds the observations of (puzzle_id, pos), the
  *                       engine its tuned launch configuration; returns the tuner's index (>= 0).  candidate_ms (host
  *                       float [max_candidates], may be NULL) receives every candidate's screened time, *tried how many
@@ -446,6 +466,25 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
                uint8_t* truncated, double* reward_hist, uint8_t* terminated_hist,
                uint8_t* truncated_hist, int32_t batch, uint32_t flags, void* stream);
 
+/* BATCH BINDING: stepping at LDS-table speed for batches whose puzzle ids are known in advance (configs C2 .. C4 state-only; the
+ * step half of pw_step_render).  Every pw_step / pw_rollout call takes puzzle_id afresh and walks id -> header -> table rows through
+ * the caches for every push test (get_next_state, puzzle.py:348-394).  pw_batch_bind reads the ids ONCE and cuts the batch into
+ * segments -- up to 256 environments of one puzzle, consecutive or not --; from then on every stepping call that passes THE SAME
+ * puzzle_id pointer and batch size launches one workgroup per segment, which copies its puzzle's push tables (the reference's collision
+ * tables, puzzle.py:259-311, all four actions in one nibble per offset; median 3 KB) into LDS and steps one lane per environment.
+ * Environments of puzzles played by fewer than PW_OPT_BIND_MIN_ENVS environments of the batch (a C4 shard's Level-0 half: 2 per
+ * puzzle), or whose tables exceed 16 KB of LDS, keep the lane groups -- in the same launch.  Same results as unbound calls, bit for bit.
+ *   - ONE binding per engine; binding again replaces it; every other call (other pointers / batch sizes, pw_step_render_delta,
+ *     pw_mailbox_*) works unbound as before;
+ *   - the binding is a promise about the CONTENTS of puzzle_id: change them only through pw_resample or before a pw_reset on that
+ *     buffer (both rebuild the list behind themselves, on their stream, without a host round trip), or bind again.  An environment
+ *     whose id changed otherwise is played on the puzzle it was bound to (memory-safe; counted: PW_OPT_BIND_MISMATCHES);
+ *   - pw_batch_bind synchronises `stream` (it reads the number of segments back); info (optional, int64 [4]) receives the number of
+ *     segments, bound environments, bound puzzles, and how many of those needed an index list (their environments not consecutive).
+ * Measured (one C4 shard, 65 536 environments): DESIGN.md section 4 K1g. */
+int pw_batch_bind(PwEngine* e, const int32_t* puzzle_id, int32_t batch, int64_t* info, void* stream);
+int pw_batch_unbind(PwEngine* e);
+
 /* RESIDENT stepping of a small state-only batch ("mailbox"): gym_env.py:188-226 for a host that needs every step's verdicts
  * before it chooses the next actions, without a kernel launch and a stream synchronisation per step.  pw_mailbox_open starts a
  * kernel that keeps the batch in registers and waits; pw_mailbox_post hands it the actions of ONE step (a word in pinned memory:
@@ -464,7 +503,11 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
  *   - the kernel ends by pw_mailbox_close, or BY ITSELF after idle_ms (0 = 1 000) without a post: a resident kernel would
  *     otherwise hold every device-wide synchronisation (hipDeviceSynchronize, torch.cuda.synchronize) for ever.  pw_mailbox_post
  *     fails with PW_EDEVICE once more than idle_ms / 2 have passed since the previous post (the mailbox has expired: close it
- *     and open a new one; the arrays hold the state after the last complete step).
+ *     and open a new one; the arrays hold the state after the last complete step -- the Python Mailbox does exactly that by itself
+ *     when no step is in flight).  Consequences for the caller: (i) a host that pauses between steps (a learner update, logging)
+ *     for longer than idle_ms / 2 loses the kernel -- choose idle_ms for the longest pause of the loop; (ii) ANY device-wide
+ *     synchronisation while a mailbox is open (hipDeviceSynchronize, a hipFree / hipMalloc of another allocator on the device,
+ *     pw_obs_free, destroying another engine) stalls until the kernel idles out, i.e. up to idle_ms, and ends the mailbox.
  *   - one host thread at a time per mailbox (post / wait / step / run / close are not synchronised against each other).
  * Measured (C2, 4 096 environments, tools/bench_mailbox.py, profiles/r05_mailbox.json): 6.1 us per synchronous step against 17.8 us
  * for pw_step + a stream synchronisation; 3.2 us with 8 steps in flight.  DESIGN.md K1f. */

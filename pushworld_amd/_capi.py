@@ -112,6 +112,8 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_void_p, c_int32, c_uint32, c_void_p],
     ),
+    "pw_batch_bind": (c_int, [c_void_p, c_void_p, c_int32, POINTER(c_int64), c_void_p]),
+    "pw_batch_unbind": (c_int, [c_void_p]),
     "pw_mailbox_open": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint32, c_int32, c_int32,
@@ -211,6 +213,14 @@ OPTIONS = {
     "step_quad16_puzzles": 32, # read-only: puzzles of the set that fit
     "mailbox_mode": 35,        # pw_mailbox_open: 0 / 1 / 2 who polls the host's word (every wavefront / one per workgroup / one), + 4 fences
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
+    "obs_tune_ms": 40,         # pw_obs_alloc_tuned: wall-clock budget of the candidate screen (0 = default 10 000 ms)
+    "obs_screen_ms": 41,       # read-only: what the last screen took
+    "bind_min_envs": 36,       # pw_batch_bind: environments of a batch that must play a puzzle for it to be bound (0 = default 48)
+    "bind_fused": 37,          # launches of a bound batch: 0 / "auto" one launch for segments + lane groups, 2 two launches
+    "bind_rollouts": 43,       # pw_rollout on a bound batch: 0 / "auto" segments when every environment is bound, 1 always, 2 never
+    "bind_lanes": 42,          # lanes per environment of the segments: 0 automatic, 1 / 2 / 3 = at most 1 / 2 / 4
+    "bind_puzzles": 38,        # read-only: puzzles of the set that can be bound (table block within 16 KB of LDS)
+    "bind_mismatches": 39,     # read-only: environments found with another puzzle id than the one they were bound to
 }
 _OPTION_VALUES = {"group": 0, "wave": 1, "lane": 2, "auto": 0, "page": 0, "lds": 1, "big": 3, "all": 1, "none": 2,
                   "forward": 0, "reverse": 1, "never": 2**31}
@@ -448,12 +458,26 @@ class Mailbox:
     the actions of a step -- no launch, no stream synchronisation.  ``post`` returns the step's number, ``wait`` the verdicts of
     that step as numpy views of pinned host memory (valid until ``ring`` more steps have been posted), ``step`` does both.
     The arrays given here receive after every step what ``pw_step`` would have written.  A context manager: the kernel ends at
-    ``close`` (or by itself after ``idle_ms`` without a post -- ``post`` then raises RuntimeError)."""
+    ``close``, or by itself after ``idle_ms`` without a post (a resident kernel would hold every device-wide synchronisation --
+    ``torch.cuda.synchronize``, a ``hipFree`` of torch's allocator, destroying another engine -- for ever; such a call made
+    while a mailbox is open costs up to ``idle_ms`` and ends the kernel).  A ``post`` / ``step`` / ``run`` that finds the mailbox
+    expired with no step in flight opens it again by itself (``reopened`` counts it: the arrays hold the state after the last
+    complete step); with steps in flight it raises RuntimeError.  For loops that pause between steps (learner updates) raise
+    ``idle_ms``: a pause shorter than ``idle_ms / 2`` costs nothing."""
 
     def __init__(self, engine, puzzle_id, pos, steps, reward, dgoals, terminated, truncated, flags=0, ring=8, idle_ms=1000):
         self.engine = engine
         self.batch = int(pos.shape[0])
         self._keep = (puzzle_id, pos, steps, reward, dgoals, terminated, truncated)
+        self._open_args = (int(flags), int(ring), int(idle_ms))
+        self.reopened = 0  # how often an expired mailbox was opened again (see _revive)
+        self.handle = None
+        self._open()
+
+    def _open(self):
+        engine = self.engine
+        puzzle_id, pos, steps, reward, dgoals, terminated, truncated = self._keep
+        flags, ring, idle_ms = self._open_args
         torch.cuda.current_stream(engine.device).synchronize()  # what was queued for these arrays is complete
         handle = c_void_p()
         check(lib.pw_mailbox_open(engine.handle, _ptr(puzzle_id), _ptr(pos), _ptr(steps), _ptr(reward), _ptr(dgoals),
@@ -463,6 +487,7 @@ class Mailbox:
         engine._mailbox = weakref.ref(self)
         self._seq = ctypes.c_uint64()
         self._seq_ref = ctypes.byref(self._seq)
+        self._waited = 0  # the highest step number a wait has returned (steps posted beyond it are in flight)
         self._out = (c_void_p(), c_void_p(), c_void_p())
         # numpy views of the pinned result slots, made once (a view per call costs more than the step)
         base, stride, ot, ou, rg = c_void_p(), c_int64(), c_int64(), c_int64(), c_int32()
@@ -475,6 +500,20 @@ class Mailbox:
             s = raw[i * stride.value:(i + 1) * stride.value]
             self._slots.append((s[:8 * B].view(np.float64), s[ot.value:ot.value + B], s[ou.value:ou.value + B]))
 
+    def _revive(self, rc) -> bool:
+        """A post that failed because the mailbox EXPIRED -- the host paused for more than ``idle_ms / 2`` (a learner update, logging,
+        garbage collection), or a device-wide synchronisation made the resident kernel run into its idle limit -- with no step in
+        flight: the arrays hold the state after the last complete step, so the mailbox is closed and opened again and the post
+        retried.  (Step numbers restart at 1; with steps in flight the caller still holds numbers of the old kernel: the error is
+        raised as before.)"""
+        if rc != PW_EDEVICE or self._seq.value != self._waited or b"expired" not in (lib.pw_last_error() or b""):
+            return False
+        handle, self.handle = self.handle, None
+        lib.pw_mailbox_close(handle)
+        self._open()
+        self.reopened += 1
+        return True
+
     def post(self, actions) -> int:
         """``actions``: uint8 [B], a numpy array (host) or a tensor on the engine's device (torch's current stream is
         synchronised first: the resident kernel is not in any stream's order)."""
@@ -483,19 +522,26 @@ class Mailbox:
         if isinstance(actions, np.ndarray):
             if actions.dtype != np.uint8 or actions.shape != (self.batch,) or not actions.flags.c_contiguous:
                 raise ValueError("actions must be a contiguous uint8 array of shape [num_envs]")
-            check(lib.pw_mailbox_post(self.handle, c_void_p(actions.ctypes.data), 1, ctypes.byref(self._seq)))
+            rc = lib.pw_mailbox_post(self.handle, c_void_p(actions.ctypes.data), 1, self._seq_ref)
+            if rc and self._revive(rc):
+                rc = lib.pw_mailbox_post(self.handle, c_void_p(actions.ctypes.data), 1, self._seq_ref)
+            check(rc)
         else:
             if actions.dtype != torch.uint8 or tuple(actions.shape) != (self.batch,) or not actions.is_contiguous() \
                     or actions.device != self.engine.device:
                 raise ValueError("actions must be a contiguous uint8 tensor of shape [num_envs] on the engine's device")
             torch.cuda.current_stream(self.engine.device).synchronize()  # (the kernel that produced them has finished)
-            check(lib.pw_mailbox_post(self.handle, _ptr(actions), 0, ctypes.byref(self._seq)))
+            rc = lib.pw_mailbox_post(self.handle, _ptr(actions), 0, self._seq_ref)
+            if rc and self._revive(rc):
+                rc = lib.pw_mailbox_post(self.handle, _ptr(actions), 0, self._seq_ref)
+            check(rc)
         return self._seq.value
 
     def wait(self, seq: int):
         if self.handle is None:
             raise RuntimeError("the mailbox is closed")
         check(lib.pw_mailbox_wait(self.handle, seq, None, None, None))
+        self._waited = max(self._waited, int(seq))
         return self._slots[(seq - 1) % self.ring]
 
     def step(self, actions):
@@ -506,14 +552,19 @@ class Mailbox:
             if actions.dtype != np.uint8 or actions.shape != (self.batch,) or not actions.flags.c_contiguous:
                 raise ValueError("actions must be a contiguous uint8 array of shape [num_envs]")
             rc = lib.pw_mailbox_step(self.handle, actions.ctypes.data, 1, self._seq_ref)
+            if rc and self._revive(rc):
+                rc = lib.pw_mailbox_step(self.handle, actions.ctypes.data, 1, self._seq_ref)
         else:
             if actions.dtype != torch.uint8 or tuple(actions.shape) != (self.batch,) or not actions.is_contiguous() \
                     or actions.device != self.engine.device:
                 raise ValueError("actions must be a contiguous uint8 tensor of shape [num_envs] on the engine's device")
             torch.cuda.current_stream(self.engine.device).synchronize()  # (the kernel that produced them has finished)
             rc = lib.pw_mailbox_step(self.handle, actions.data_ptr(), 0, self._seq_ref)
+            if rc and self._revive(rc):
+                rc = lib.pw_mailbox_step(self.handle, actions.data_ptr(), 0, self._seq_ref)
         if rc:
             check(rc)
+        self._waited = self._seq.value
         return self._slots[(self._seq.value - 1) % self.ring]
 
     def run(self, actions, ahead: int = 1) -> int:
@@ -531,7 +582,11 @@ class Mailbox:
             ptr = _ptr(actions)
         if not ok:
             raise ValueError("actions must be a contiguous uint8 array / tensor of shape [T, num_envs]")
-        check(lib.pw_mailbox_run(self.handle, ptr, int(actions.shape[0]), 1 if host else 0, int(ahead), ctypes.byref(self._seq)))
+        rc = lib.pw_mailbox_run(self.handle, ptr, int(actions.shape[0]), 1 if host else 0, int(ahead), self._seq_ref)
+        if rc and self._revive(rc):
+            rc = lib.pw_mailbox_run(self.handle, ptr, int(actions.shape[0]), 1 if host else 0, int(ahead), self._seq_ref)
+        check(rc)
+        self._waited = self._seq.value
         return self._seq.value
 
     def close(self, profile: bool = False):
@@ -893,6 +948,20 @@ class Engine:
         check(lib.pw_rollout(self.handle, _ptr(puzzle_id), _ptr(actions), actions.shape[0], _ptr(pos), _ptr(steps),
                              _ptr(reward), _ptr(dgoals), _ptr(terminated), _ptr(truncated), _ptr(reward_hist),
                              _ptr(terminated_hist), _ptr(truncated_hist), pos.shape[0], flags, self._stream()))
+
+    def bind(self, puzzle_id) -> dict:
+        """``pw_batch_bind``: from now on ``step`` / ``rollout`` / ``step_render`` calls that pass THIS ``puzzle_id`` tensor run
+        one lane per environment with the puzzle's push tables in LDS, for every puzzle that at least ``bind_min_envs``
+        environments of the batch play (the others keep the lane groups, in the same launch).  The ids may only change through
+        ``resample`` / before a ``reset`` on this tensor (both rebuild the binding), else bind again."""
+        info = (c_int64 * 4)()
+        check(lib.pw_batch_bind(self.handle, _ptr(puzzle_id), puzzle_id.shape[0], info, self._stream()))
+        self._bound = puzzle_id  # (the engine keeps the pointer: the tensor must stay alive)
+        return {"segments": info[0], "bound_envs": info[1], "bound_puzzles": info[2], "listed_puzzles": info[3]}
+
+    def unbind(self) -> None:
+        check(lib.pw_batch_unbind(self.handle))
+        self._bound = None
 
     def mailbox(self, puzzle_id, pos, steps, reward, dgoals, terminated, truncated, flags=0, ring=8, idle_ms=1000):
         """``pw_mailbox_open``: the resident step kernel over these arrays (see :class:`Mailbox`)."""

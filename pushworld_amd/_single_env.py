@@ -110,10 +110,18 @@ class SingleEnvCore:
         if signalled:
             word, want = self._signal_np, self._signalled
             for _ in range(200000):  # (~20 ms: then ask the runtime -- a failed launch must not spin for ever)
-                if word[0] == want:
+                if word[0] >= want:  # (>=: the engine's count can only run ahead of ours -- see the re-arm below)
                     break
             else:
+                # The word did not arrive: our count and the engine's have come apart (an exception between the launch and the
+                # count's increment, another caller's pw_step_render_delta on this engine) or the launch failed.  The stream
+                # says when the step is done; the word is armed again, both counts from zero.
                 torch.cuda.current_stream(self._engine.device).synchronize()
+                self._signal_np[0] = 0
+                self._signalled = 0
+                self._engine.set_step_signal(self._signal)
+            # (the observation / scalars below were written before the word by the same kernel with system-scope stores; this
+            # host's loads are not reordered before the load that saw the word -- x86; another host ISA needs an acquire fence here)
         else:
             torch.cuda.current_stream(self._engine.device).synchronize()
         return self._obs_np.copy(), self._raw_np

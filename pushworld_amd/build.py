@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpushworld_amd.so")
 SOURCES = ["pw_host.cpp", "pw_kernels.hip"]
-HEADERS = ["pw_host.h", "pw_format.h", "pw_zone.h", "pw_device_guard.h", "pw_search.inc", "pw_generate.inc", "pw_step_kernels.inc", "pw_mailbox_kernels.inc", "pw_expand_kernels.inc", "pw_mailbox.inc", "pw_render_kernels.inc",
+HEADERS = ["pw_host.h", "pw_format.h", "pw_zone.h", "pw_device_guard.h", "pw_search.inc", "pw_generate.inc", "pw_step_kernels.inc", "pw_seg_kernels.inc", "pw_mailbox_kernels.inc", "pw_expand_kernels.inc", "pw_mailbox.inc", "pw_render_kernels.inc",
            "pw_engine.inc", os.path.join("..", "..", "include", "pushworld_amd.h")]
 ARCH = "gfx950"
 

@@ -96,6 +96,24 @@ struct PwObsBuf {
 };
 
 struct PwMailbox;
+struct PwSegDir;
+struct PwSegDesc;
+// A bound batch (pw_batch_bind): the segment list of ONE (puzzle_id buffer, batch size) pair per engine, built on the device.
+struct PwBind {
+  const int32_t* puzzle_id;  // the key: calls that pass this pointer and this batch size take the bound launches
+  int32_t batch;
+  int32_t* d_ints;           // one allocation: cnt / mn / mx / seg_base / perm_base [P each], rank / perm [B each], meta [8]
+  int32_t *cnt, *mn, *mx, *seg_base, *perm_base, *rank, *perm, *meta;
+  uint8_t* d_bound;          // [B]
+  PwSegDesc* d_segs;         // [seg_cap]
+  int32_t seg_cap;           // upper bound of the number of segments of any assignment: B / 256 + min(P, B / min_envs) + 1
+  int32_t seg_grid;          // workgroups the segment role is launched with: the exact number after pw_batch_bind (which reads
+                             // it back), seg_cap after an asynchronous re-bind (pw_resample / pw_reset on the bound buffer)
+  int32_t min_envs;
+  int64_t info[4];           // segments, bound environments, bound puzzles, of them with an index list (as of the last pw_batch_bind)
+  uint32_t lds_bytes;        // dynamic LDS of the launches: the largest block among the bound puzzles (after an asynchronous re-bind:
+                             // the largest block of the set)
+};
 struct PwEngine {
   const PwPuzzleSet* set;
   PwEngineConfig cfg;
@@ -165,6 +183,8 @@ struct PwEngine {
   std::vector<PwObsBuf> obs_bufs;  // pw_obs_alloc
   int obs_chunk_mb;        // PW_OPT_OBS_CHUNK_MB: physical chunk size of pw_obs_alloc in MiB (0 = the default, 32 MiB)
   int obs_accept_gbs;      // PW_OPT_OBS_ACCEPT_GBS: pw_obs_alloc_tuned keeps the first candidate that reaches this
+  int64_t obs_tune_ms;     // PW_OPT_OBS_TUNE_MS: wall-clock budget of pw_obs_alloc_tuned's candidate screen (0 = 10 000)
+  int64_t obs_screen_ms;   // PW_OPT_OBS_SCREEN_MS: what the last screen took
   // PW_OPT_PROFILE_RENDER: HIP event pairs around the dominant (render) launch, on the launch stream
   std::vector<hipEvent_t> prof_events;  // 2 per slot
   int prof_used;
@@ -181,6 +201,17 @@ struct PwEngine {
   size_t lat_bytes;
   uint32_t lat_seq;        // completion word of the last launch
   std::mutex lat_mu;       // pw_next_state / pw_plan_states share lat_host and lat_seq: one call at a time per engine
+  PwSegDir* d_seg_dir;     // [set size] LDS blocks of the segment kernels (pw_seg_kernels.inc), inside d_ovl; NULL without overlap tables
+  int seg_puzzles;         // puzzles with a block
+  uint32_t seg_max_bytes;  // the largest block of the set
+  hipStream_t side_stream; // launches of several steps on a partly bound batch: the segments run here, next to the lane groups on the
+  hipEvent_t ev_fork, ev_join;  // caller's stream (fork / join by events); created on first use
+  PwBind* bind;            // pw_batch_bind, or NULL
+  int bind_min_envs;       // PW_OPT_BIND_MIN_ENVS (0 = default)
+  int bind_rollouts;       // PW_OPT_BIND_ROLLOUTS: launches of several steps take the segments: 0 when every environment is bound, 1 always, 2 never
+  int bind_lanes;          // PW_OPT_BIND_LANES: 0 automatic, k = at most 2^(k - 1) lanes per environment
+  int bind_fused;          // PW_OPT_BIND_FUSED: 0 automatic, 2 never (segments and lane groups as two launches)
+  uint32_t* d_bind_mismatch;  // device counter (StepArgs::bind_mismatch)
   PwMailbox* mailbox;     // the open resident step kernel of this engine (pw_mailbox_open), or NULL
   int mailbox_mode;       // PW_OPT_MAILBOX_MODE
   unsigned long long* step_signal;     // pw_engine_set_step_signal: completion word of pw_step_render_delta on a batch of one

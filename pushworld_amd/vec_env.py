@@ -57,6 +57,10 @@ class VecPushWorld:
             alive at once, keeps the first of the fast class, releases the others to the DEVICE and tunes on the kept one (nothing stays behind in
             torch's caching allocator).  ``self.obs`` is bound once, in the constructor.  0: a plain torch buffer,
             tuned in place.
+        bind: ``pw_batch_bind`` the puzzle assignment at every ``reset`` (and behind every device-side ``resample``): puzzles played by
+            at least 48 environments of the batch are stepped one lane per environment with their push tables in LDS instead of by
+            lane groups walking the tables through the caches.  Default (None): on, except for sets of 8 x 8 puzzles
+            (whole-grid boards in registers), ``incremental`` and ``resample`` (a binding is rebuilt behind every ``pw_resample``).  Same results either way.
         engine_options: ``pw_engine_set_option`` settings (``_capi.OPTIONS``), e.g. ``{"step_kernel": "lane"}`` --
             kernel selection for tests and A/B runs; results never depend on them.
     """
@@ -67,7 +71,7 @@ class VecPushWorld:
                  observation: Optional[str] = "float32", pad_cells=None, device: Optional[int] = None,
                  autoreset: bool = False, fused: bool = True, resample=False, seed: int = 0,
                  incremental: bool = False, engine_options: Optional[dict] = None, tune: Optional[bool] = None,
-                 tune_allocations: Optional[int] = None):
+                 tune_allocations: Optional[int] = None, bind: Optional[bool] = None):
         if observation not in ("uint8", "float32", None):
             raise ValueError("observation must be 'uint8', 'float32' or None")
         dev = default_device_index() if device is None else int(device)
@@ -94,6 +98,12 @@ class VecPushWorld:
         self.fused = bool(fused)
         self.incremental = bool(incremental)
         self._obs_current = False  # the observation buffer holds the observation of self.pos
+        if bind is None:
+            # (not with `resample`: every step would rebuild the binding behind its pw_resample -- three small launches)
+            bind = not self.incremental and self.engine.get_option("bind_puzzles") > 0 and self.engine.get_option("step_board_set") == 0 \
+                and "step_kernel" not in (engine_options or {}) and (resample is False or resample is None)
+        self._bind = bool(bind)
+        self.bound_info = None  # what the last pw_batch_bind reported (segments, bound environments / puzzles)
 
         if puzzle_ids is None:
             ids = np.arange(self.num_envs) % self.num_puzzles
@@ -196,6 +206,8 @@ class VecPushWorld:
     def set_puzzle_ids(self, puzzle_ids) -> None:
         self._obs_current = False
         self.puzzle_id.copy_(torch.as_tensor(np.asarray(puzzle_ids), dtype=torch.int32))
+        if self._bind and self.bound_info is not None:
+            self.bound_info = self.engine.bind(self.puzzle_id)
 
     def reset(self, mask: Optional[torch.Tensor] = None, seed: Optional[int] = None):
         """gym_env.py:150-186 for every (masked) environment; returns the observation tensor.
@@ -209,6 +221,8 @@ class VecPushWorld:
             self.engine.resample(self.puzzle_id, self.episode, self.seed, terminated=mask, table=self.sample_table)
         self.engine.reset(self.puzzle_id, self.pos, self.steps, self.terminated, self.truncated, mask)
         self._has_reset = True
+        if self._bind and (self.bound_info is None or self.resample or mask is None):
+            self.bound_info = self.engine.bind(self.puzzle_id)  # (reads the segment count back: later launches have the exact grid)
         if self.obs is not None:
             self.engine.render(self.puzzle_id, self.pos, self._obs_storage)
             self._obs_current = True

@@ -87,7 +87,7 @@ def test_self_spawned_two_ranks_sum_their_counters():
     assert len(r["per_rank_frac"]) == 2 and all(0 < f < 1 for f in r["per_rank_frac"])
     assert len(r["per_rank_avg_launch_ms"]) == 2 and r["per_rank_avg_launch_ms"][0] == pytest.approx(r["avg_launch_ms"])
     pr = d["config"]["render_launch"]["per_rank"]
-    assert len(pr) == 2 and all(set(x) == {"tuned_ms", "allocations_tried", "fast_class"} for x in pr)
+    assert len(pr) == 2 and all(set(x) == {"tuned_ms", "allocations_tried", "fast_class", "screen_s", "constructor_s"} for x in pr)
     assert len(d["timing"]["numa_node_per_rank"]) == 2
     se = d["scaling_efficiency"]
     assert se["n1_value"] == pytest.approx(lines1[0]["value"]) and "on this host" in se["n1_source"]
@@ -138,6 +138,12 @@ def test_eight_ranks_sharing_the_device_report_eight_rows():
     assert len(d["config"]["render_launch"]["per_rank"]) == 8
     assert len(d["timing"]["per_rank_median_ms_per_step"]) == 8 and len(d["timing"]["numa_node_per_rank"]) == 8
     assert d["counters"]["env_steps"] == 8 * 1024 * 2 * 2
+    # every rank says what its constructor and, inside it, the allocator's candidate screen cost; the screen stays within its
+    # wall-clock budget (PW_OPT_OBS_TUNE_MS) plus one candidate -- eight ranks screening at once on one node must not look like a hang
+    rl = d["config"]["render_launch"]
+    assert rl["screen_budget_s"] == 10.0 and "fast_class" in rl and rl["constructor_s"] > 0
+    for row in rl["per_rank"]:
+        assert 0 <= row["screen_s"] <= rl["screen_budget_s"] + 2.0 and row["screen_s"] <= row["constructor_s"] + 0.01, row
     # a stale or missing N = 1 record is refused, not labelled
     se = d["scaling_efficiency"]
     assert se["value"] is None or "on this host" in se["n1_source"]

@@ -163,11 +163,21 @@ def test_idle_limit_ends_the_kernel():
     t0 = time.time()
     torch.cuda.synchronize()  # the kernel has ended by itself: a device-wide synchronisation returns
     assert time.time() - t0 < 1.0
-    with pytest.raises(RuntimeError):
-        mb.post(acts[2])
-    mb.close()
-    for t in range(2):
+    # ... and the next post finds the mailbox expired with no step in flight: it is opened again over the same arrays (they hold
+    # the state after the last complete step) and the step is posted to the new kernel
+    seq = mb.post(acts[2])
+    assert mb.reopened == 1 and seq == 1
+    mb.wait(seq)
+    for t in range(3):
         b.step(torch.as_tensor(acts[t]).to(b.device))
+    assert (a.pos.cpu() == b.pos.cpu()).all() and (a.steps.cpu() == b.steps.cpu()).all()
+    # with a step in flight (posted, not waited for) the caller still holds a number of the old kernel: the error is raised
+    mb.post(acts[3])
+    time.sleep(0.45)
+    with pytest.raises(RuntimeError):
+        mb.post(acts[0])
+    mb.close()
+    b.step(torch.as_tensor(acts[3]).to(b.device))
     _same_state(a, b)  # the arrays hold the state after the last complete step
     with a.mailbox() as mb2:  # a new one carries on
         mb2.step(acts[2])

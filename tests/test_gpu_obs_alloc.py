@@ -126,6 +126,25 @@ def test_tuned_allocation_tries_candidates_and_releases_the_losers(torch_mod, ch
         del st, view
 
 
+def test_the_candidate_screen_honours_its_wall_clock_budget(torch_mod):
+    """PW_OPT_OBS_TUNE_MS: once the budget is spent no further candidate is allocated -- the best so far is kept and tuned (eight
+    ranks of one node screening up to 32 candidates each at the same time must not look like a hang to whoever launched them)."""
+    torch = torch_mod
+    vec, texts, ids = _level1(4096, tune=False)
+    ref = vec.reset().clone()
+    eng = vec.engine
+    eng.set_option("obs_accept_gbs", 100000)  # out of reach: only the budget (or the 16-candidate rule) ends the screen
+    assert eng.get_option("obs_tune_ms") == 10000  # the default
+    eng.set_option("obs_tune_ms", 1)              # spent after the first candidate
+    st, view, idx, cand = eng.alloc_obs_tuned(vec.puzzle_id, vec.pos, 12)
+    assert len(cand) == 1 and torch.equal(view, ref)
+    assert 0 <= eng.get_option("obs_screen_ms") < 2000
+    del st, view
+    eng.set_option("obs_tune_ms", 0)              # back to the default: several candidates again
+    st, view, idx, cand = eng.alloc_obs_tuned(vec.puzzle_id, vec.pos, 4)
+    assert len(cand) >= 2 and torch.equal(view, ref)
+
+
 def test_vec_env_binds_its_observation_once(torch_mod):
     torch = torch_mod
     reserved0 = torch.cuda.memory_reserved()

@@ -29,8 +29,10 @@ def puzzles(golden):
 
 
 def _groups(golden, puzzles=None):
-    g = {"bench": [], "tests": [], "l0": [], "level1": [], "tiny": []}
+    g = {"bench": [], "tests": [], "l0": [], "level1": [], "tiny": [], "bench+tests": []}
     for k in golden.keys:
+        if not k.startswith("l0:"):  # benchmark puzzles (three sequences each) + test / random ones (two): with bind_min_envs 3 the
+            g["bench+tests"].append(k)  # first are bound, the second go through the lane-group role of the same launch
         if puzzles is not None:  # grid with its border walls within 8 x 8, at most 8 movables: pw_step_board_kernel's sets
             w, h = puzzles[k].dimensions
             if w <= 8 and h <= 8 and puzzles[k].num_movables <= 8:  # (dimensions include the border)
@@ -51,6 +53,15 @@ def _step_options(kernel):
     steps; pools with more than 16 movables per puzzle: two per lane), "group-lds" (row tables staged in LDS, the
     default of multi-step rollouts), "group-wide" (32-lane groups), "lane", "wave"; "group-tables" / "group-notables":
     overlap tables (PW_OPT_STEP_TABLES) for every puzzle / for none (default: for puzzles with movables beyond 8 x 8)."""
+    if kernel.startswith("bound"):
+        # a BOUND batch (pw_batch_bind; VecPushWorld(bind=True)): segments of one puzzle each, one lane per environment, push tables
+        # in LDS.  "bound": every puzzle of the batch bound (min_envs 1); "bound-split": segments and lane groups as two launches;
+        # "bound-mixed": only the puzzles with at least 3 environments bound, the others through the lane-group role of the launch
+        opts = {"step_boards": "never", "step_lds_tables": 2, "bind_min_envs": 3 if kernel == "bound-mixed" else 1,
+                "bind_rollouts": 1}  # (launches of several steps: segments next to the lane groups also where only some are bound)
+        if kernel == "bound-split":
+            opts["bind_fused"] = 2
+        return opts
     if kernel == "group-noquad":  # the defaults without the 16 x 16 whole-grid boards (the lane groups for every workgroup)
         return {"step_kernel": "group", "step_lds_tables": 2, "step_boards": "never", "step_quad16": "never"}
     if kernel == "group-narrow":  # N_pad 16 pools: 8 lanes per environment, two movables per lane
@@ -94,7 +105,9 @@ def _step_options(kernel):
                                           ("bench", "big-batch"), ("l0", "big-batch"),
                                           ("tiny", "boards"), ("tiny", "group"),
                                           ("l0", "group-noquad"), ("tiny", "group-noquad"), ("level1", "group-noquad"), ("tests", "group-noquad"),
-                                          ("bench", "wave"), ("tests", "wave")])
+                                          ("bench", "wave"), ("tests", "wave"),
+                                          ("bench", "bound"), ("tests", "bound"), ("l0", "bound"), ("level1", "bound"), ("tiny", "bound"),
+                                          ("bench", "bound-split"), ("l0", "bound-split"), ("bench+tests", "bound-mixed")])
 def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel, monkeypatch):
     """Every golden sequence (human plan, mid-plan random walk, random walk) of every puzzle in
     one mixed batch: positions, float64 reward bits, terminated, truncated, step counter.
@@ -114,8 +127,15 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
     T = max(len(e[2][1]) for e in envs)
     max_steps = 50
     vec = VecPushWorld(pool, B, puzzle_ids=[e[0] for e in envs], max_steps=max_steps, observation=None, device=0,
-                       engine_options=_step_options(kernel))
-    if group == "tiny":  # the set qualifies for the whole-grid boards; "boards" runs them, "group" the lane groups
+                       engine_options=_step_options(kernel), bind=kernel.startswith("bound"))
+    if kernel.startswith("bound"):
+        vec.reset()
+        # (every puzzle has a block but `Mind The Gap`; "bound-mixed": the puzzles with all three sequences)
+        if kernel == "bound-mixed":
+            assert 0 < vec.bound_info["bound_envs"] < B, vec.bound_info
+        else:
+            assert vec.bound_info["bound_envs"] > B - 1 - 3 * 8, vec.bound_info
+    elif group == "tiny":  # the set qualifies for the whole-grid boards; "boards" runs them, "group" the lane groups
         assert vec.engine.get_option("step_board_set") == 1
         assert vec.engine.get_option("step_boards") == (0 if kernel == "boards" else 2)
     vec.reset()
@@ -157,7 +177,7 @@ def test_trajectories_match_reference(golden, puzzles, torch_mod, group, kernel,
 
 
 @pytest.mark.parametrize("kernel", ["group", "group-noquad", "group-lds", "group-wide", "group-16lanes", "group-tables", "group-notables", "group-bigtables",
-                                    "lane", "lane-notables", "wave", "boards"])
+                                    "lane", "lane-notables", "wave", "boards", "bound", "bound-split"])
 def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypatch):
     """Random in-bounds states (objects may overlap each other and walls): all 4 successors
     equal the reference's table lookups (pins the not-already-overlapping clause)."""
@@ -177,7 +197,8 @@ def test_random_overlapping_states(golden, puzzles, torch_mod, kernel, monkeypat
             ids.append(pi)
             rows.append((k, s))
     B = len(ids)
-    vec = VecPushWorld(pool, B, puzzle_ids=ids, observation=None, device=0, engine_options=_step_options(kernel))
+    vec = VecPushWorld(pool, B, puzzle_ids=ids, observation=None, device=0, engine_options=_step_options(kernel),
+                       bind=kernel.startswith("bound"))
     vec.reset()
     NP = vec.num_objects_padded
     base = np.zeros((B, NP, 2), np.int8)
@@ -499,7 +520,7 @@ def test_fused_step_render_matches_reference(golden, puzzles, torch_mod, force_f
 
 
 @pytest.mark.parametrize("kernel", ["group", "group-noquad", "group-lds", "group-wide", "group-16lanes", "group-notables", "group-bigtables", "group-level1",
-                                    "group-narrow", "lane", "lane-notables", "big-batch", "boards"])
+                                    "group-narrow", "lane", "lane-notables", "big-batch", "boards", "bound", "bound-split", "bound-mixed"])
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, kernel, monkeypatch):
     """pw_rollout (T steps in one launch) == T pw_step launches: final state and every step's
@@ -531,10 +552,13 @@ def test_rollout_equals_repeated_steps(golden, puzzles, torch_mod, autoreset, ke
     acts = torch.as_tensor(actions).to("cuda:0")
     ids = [e[0] for e in envs]
     opts = _step_options(kernel)
+    if kernel == "bound-mixed":
+        opts["bind_min_envs"] = 2  # (benchmark puzzles: plan + random walk = two environments each -> bound; the others one)
+    bind = kernel.startswith("bound")
     a = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset,
-                     engine_options=opts)
+                     engine_options=opts, bind=bind)
     b_ = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=40, observation=None, device=0, autoreset=autoreset,
-                      engine_options=opts)
+                      engine_options=opts, bind=bind)
     a.reset()
     b_.reset()
     rh, th, uh = a.rollout(acts, history=True)

@@ -20,7 +20,7 @@ TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 CONFIG_KEYS = ("workload", "config", "envs_per_gpu", "global_batch", "puzzles", "frame_cells", "pixels_per_cell", "border_width",
                "observation", "obs_shape", "max_steps", "autoreset", "n_pad", "parallelism", "ranks_in_probe_all_reduce",
                "algorithmic_bytes_per_env_step")
-ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "traffic", "traffic_ratio",
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "traffic", "traffic_ratio", "traffic_from",
                  "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_timed", "timer")
 SUB_KEYS = ("value", "unit", "kernel", "avg_launch_ms", "frac", "hbm_frac", "traffic_ratio")
 
@@ -96,7 +96,10 @@ def compact_line(full, full_path=None):
     out["config"] = {k: cfg[k] for k in CONFIG_KEYS if k in cfg}
     rl = cfg.get("render_launch")
     if isinstance(rl, dict):
-        out["config"]["render_launch"] = {k: rl[k] for k in ("tuned_index", "tuned_ms", "allocations_tried") if k in rl}
+        # (which of the two buffer classes the allocator found decides 0.86 vs 0.875 of peak: a slow-class box must not read as a
+        # regression; constructor_s / screen_s: what the screen of up to 32 candidates cost)
+        out["config"]["render_launch"] = {k: rl[k] for k in ("tuned_index", "tuned_ms", "allocations_tried", "fast_class", "constructor_s",
+                                                             "screen_s") if k in rl}
     if "roofline" in full:
         out["roofline"] = compact_roofline(full["roofline"])
     if "cpu_baseline" in full:
