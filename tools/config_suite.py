@@ -52,7 +52,7 @@ def csrc_sha():
 # which kernel sources a configuration's PMC record describes (its dominant kernel's translation-unit pieces): a record stays
 # valid while THESE files are unchanged -- a tweak to the search kernels does not invalidate the render records
 _RENDER_SRC = ("pw_render_kernels.inc", "pw_zone.h", "pw_format.h")
-_STEP_SRC = ("pw_step_kernels.inc", "pw_format.h")
+_STEP_SRC = ("pw_step_kernels.inc", "pw_seg_kernels.inc", "pw_format.h")  # (bound batches: the segment role lives in pw_seg_kernels.inc)
 _EXPAND_SRC = ("pw_expand_kernels.inc", "pw_format.h")  # (pw_expand4_v2*_kernel: self-contained in that file)
 KEY_SOURCES = {"C3_f32_ppc3": _RENDER_SRC, "C3_f32_ppc20_8192": _RENDER_SRC, "C4_u8_ppc3": _RENDER_SRC,
                "C4_state": _STEP_SRC, "C4_rollout": _STEP_SRC, "C2_step": _STEP_SRC, "C2_rollout": _STEP_SRC,
