@@ -319,6 +319,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_BIND_ROLLOUTS 43      /* launches of several steps (pw_rollout) on a bound batch: 0 (default) the segments when EVERY environment of the batch
                                       is bound, else the lane groups for all of them (measured: next to lane groups that fill the chip the
                                       segment role does not finish sooner); 1 always (segments and lane groups side by side on two streams), 2 never */
+#define PW_OPT_BIND_MAX_KB 44        /* pw_batch_bind (read when binding): puzzles whose table block exceeds this many KiB of LDS stay with the lane groups
+                                      (0 = default 48: every benchmark puzzle is bound; the launches carry as much LDS as the largest BOUND block) */
 #define PW_OPT_OBS_TUNE_MS 40        /* pw_obs_alloc_tuned: wall-clock budget of the candidate screen in milliseconds (0 = default 10 000): no
                                       further candidate is allocated once it is spent (the best so far is kept and tuned) -- bounds the
                                       constructor when several ranks of a node screen at the same time */

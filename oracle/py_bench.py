@@ -9,7 +9,7 @@ import numpy as np
 
 
 def run(job):
-    """job: texts, max_steps, render, pad_h, pad_w, ppc, bw, seconds, seed.  Returns steps, seconds and the time
+    """job: texts, max_steps, render, pad_h, pad_w, ppc, bw, seconds, seed, obs_dtype ("u8" default / "f32").  Returns steps, seconds and the time
     spent building the collision tables (puzzle.py:259-311 restated; not part of the rate)."""
     from oracle import pw_oracle
 
@@ -25,7 +25,10 @@ def run(job):
         for e in envs:
             state, _, term, trunc = e.step(int(rng.integers(0, 4)))
             if job["render"]:
-                e.puzzle.observation_u8(state, job["pad_h"], job["pad_w"], job["ppc"], job["bw"])
+                if job.get("obs_dtype") == "f32":  # what gym_env.py:188-226 returns: uint8 -> float32 / 255, zero padded
+                    e.puzzle.observation(state, job["pad_h"], job["pad_w"], job["ppc"], job["bw"])
+                else:
+                    e.puzzle.observation_u8(state, job["pad_h"], job["pad_w"], job["ppc"], job["bw"])
             if term or trunc:
                 e.reset()
             steps += 1

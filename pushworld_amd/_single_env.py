@@ -7,6 +7,7 @@ puzzle id.
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import Optional
 
@@ -102,6 +103,12 @@ class SingleEnvCore:
         self._signalled = 0
         self._engine.set_step_signal(self._signal)
         self._stream = torch.cuda.current_stream(dev_t)
+        # One GRAPH launch per step: the step's two launches (step kernel, redraw of the changed rows + completion
+        # word) are captured once per action -- the action is a byte of self._acts, i.e. part of the captured pointer; four graphs --
+        # and replayed: one runtime call instead of two kernel launches.  Captured after a few eager steps (first calls may
+        # allocate); PUSHWORLD_AMD_STEP_GRAPHS=0 keeps the eager launches (A/B runs).
+        self._graphs = None if os.environ.get("PUSHWORLD_AMD_STEP_GRAPHS", "1") != "0" else False
+        self._eager_steps = 0
 
     # ------------------------------------------------------------------
     def _read_back(self, signalled: bool = False):
@@ -122,6 +129,42 @@ class SingleEnvCore:
                 self._engine.set_step_signal(self._signal)
             # (the observation / scalars below were written before the word by the same kernel with system-scope stores; this
             # host's loads are not reordered before the load that saw the word -- x86; another host ISA needs an acquire fence here)
+        else:
+            torch.cuda.current_stream(self._engine.device).synchronize()
+        return self._obs_np.copy(), self._raw_np
+
+    def _capture_graphs(self) -> None:
+        """Four HIP graphs, one per action, of this environment's step (``torch.cuda.CUDAGraph`` over the library's launches: they go
+        to torch's current stream and neither allocate nor synchronise).  A captured launch does not run, but the engine counted
+        it: the completion word is armed again afterwards; a replayed step writes the (non-zero) number its capture baked in, so
+        the host zeroes the word before a replay and waits for anything else."""
+        dev = self._engine.device
+        try:
+            torch.cuda.synchronize(dev)
+            graphs = []
+            for a in range(4):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    rc = self._step_call(self._acts_ptr + a)
+                if rc != 1:
+                    raise RuntimeError("the captured step does not write the completion word")
+                graphs.append(g)
+            torch.cuda.synchronize(dev)
+            self._graphs = graphs
+        except Exception:  # noqa: BLE001  (a runtime without graph capture: the eager launches stay)
+            self._graphs = False
+            torch.cuda.synchronize(dev)
+        self._signal_np[0] = 0
+        self._signalled = 0
+        self._engine.set_step_signal(self._signal)
+
+    def _graph_step(self, action: int):
+        word = self._signal_np
+        word[0] = 0
+        self._graphs[action].replay()
+        for _ in range(200000):
+            if word[0] != 0:
+                break
         else:
             torch.cuda.current_stream(self._engine.device).synchronize()
         return self._obs_np.copy(), self._raw_np
@@ -148,10 +191,16 @@ class SingleEnvCore:
         if not 0 <= action <= 3:  # (the adapters have checked their action spaces; the pointer arithmetic below must not run wild)
             raise ValueError("The provided action is not in the action space.")
         # the observation buffer is this environment's own and always current: incremental redraw (pw_step_render_delta)
-        signalled = self._step_call(self._acts_ptr + action) == 1
-        if signalled:
-            self._signalled += 1
-        observation, raw = self._read_back(signalled)
+        if self._graphs:
+            observation, raw = self._graph_step(action)
+        else:
+            signalled = self._step_call(self._acts_ptr + action) == 1
+            if signalled:
+                self._signalled += 1
+            observation, raw = self._read_back(signalled)
+            self._eager_steps += 1
+            if self._graphs is None and signalled and self._eager_steps >= 8:
+                self._capture_graphs()
         self._steps += 1
         n = self._current_puzzle.num_movables
         xy = raw[16:16 + 2 * n].view(np.int8)

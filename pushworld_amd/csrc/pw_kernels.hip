@@ -208,6 +208,7 @@ struct PwEngine {
   hipEvent_t ev_fork, ev_join;  // caller's stream (fork / join by events); created on first use
   PwBind* bind;            // pw_batch_bind, or NULL
   int bind_min_envs;       // PW_OPT_BIND_MIN_ENVS (0 = default)
+  int bind_max_kb;         // PW_OPT_BIND_MAX_KB: largest block (KiB of LDS) that is bound (0 = 48)
   int bind_rollouts;       // PW_OPT_BIND_ROLLOUTS: launches of several steps take the segments: 0 when every environment is bound, 1 always, 2 never
   int bind_lanes;          // PW_OPT_BIND_LANES: 0 automatic, k = at most 2^(k - 1) lanes per environment
   int bind_fused;          // PW_OPT_BIND_FUSED: 0 automatic, 2 never (segments and lane groups as two launches)

@@ -110,6 +110,8 @@ def main():
         opts = {"bind_fused": 2} if name == "bound-split" else {}
         if name.endswith("-noquad"):
             opts["step_quad16"] = "never"
+        if "kb16" in name:
+            opts["bind_max_kb"] = 16
         for k in (1, 2, 3):
             if f"lanes{k}" in name:
                 opts["bind_lanes"] = k

@@ -221,11 +221,12 @@ def run_c1(cpu=True):
             from tools.cpu_baselines import python_env_rate, port_rollout_rate
 
             w, h = pz.dimensions
-            py_r = python_env_rate([text], 100, True, h, w, 20, 2, seconds=1.0)
+            # (the float32 / 255 observation the gym path returns -- like for like with gym_step_with_render)
+            py_r = python_env_rate([text], 100, True, h, w, 20, 2, seconds=1.0, obs_dtype="f32")
             py_s = python_env_rate([text], 100, False, h, w, 20, 2, seconds=0.6)
             cp = port_rollout_rate([text], np.zeros(64, np.int64), 100, 0, h, w, 20, 2, seconds=0.4, samples=CPU_SAMPLES, sample_envs=64, with_one_thread=False)
             out["cpu_baseline"] = {"value": py_r["value"], "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
-                                   "sample": py_r["sample"] + " [uint8 observation ppc 20]",
+                                   "sample": py_r["sample"] + " [float32 observation ppc 20, as gym_env.py:188-226 returns it]",
                                    "state_only": {"value": py_s["value"], "sample": py_s["sample"]},
                                    "c_port_state_only_all_threads": {"value": cp["value"], "cores": cp["cores"], "sample": cp["sample"]}}
     return out

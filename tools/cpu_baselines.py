@@ -203,16 +203,16 @@ def port_expand_rate(text, states, seconds=0.5, samples=3):
             "samples": vals}
 
 
-def python_env_rate(texts, max_steps, render, pad_h, pad_w, ppc, bw, seconds=2.0, processes=0):
+def python_env_rate(texts, max_steps, render, pad_h, pad_w, ppc, bw, seconds=2.0, processes=0, obs_dtype="u8"):
     """The pure-Python restatement of the reference environment (oracle/pw_oracle.py: hash-set collision tables, per-cell
     painter, /255 + np.pad -- the closest thing to the reference's own CPU Python env that can travel to the GPU box), one
     process; with ``processes`` > 0 also that many independent workers."""
     from oracle import py_bench
 
     job = dict(texts=list(texts), max_steps=max_steps, render=bool(render), pad_h=pad_h, pad_w=pad_w, ppc=ppc, bw=bw,
-               seconds=seconds)
+               seconds=seconds, obs_dtype=obs_dtype)
     one = py_bench.run(dict(job, seed=777))
-    what = f"step + padded uint8 render ppc={ppc}" if render else "step only"
+    what = (f"step + padded {'float32 (/255)' if obs_dtype == 'f32' else 'uint8'} render ppc={ppc}") if render else "step only"
     out = {"value": one["steps"] / one["seconds"], "unit": "env-steps/s", "cores": 1, "kind": "port (pure Python)",
            "sample": f"{len(texts)} puzzle(s) x {one['steps'] // max(1, len(texts))} steps, {what}, {one['seconds']:.1f} s; "
                      f"collision-table construction took {one['build_seconds']:.1f} s (not included)"}
