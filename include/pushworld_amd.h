@@ -481,8 +481,10 @@ int pw_rollout(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, in
  *   - the binding is a promise about the CONTENTS of puzzle_id: change them only through pw_resample or before a pw_reset on that
  *     buffer (both rebuild the list behind themselves, on their stream, without a host round trip), or bind again.  An environment
  *     whose id changed otherwise is played on the puzzle it was bound to (memory-safe; counted: PW_OPT_BIND_MISMATCHES);
- *   - pw_batch_bind synchronises `stream` (it reads the number of segments back); info (optional, int64 [4]) receives the number of
- *     segments, bound environments, bound puzzles, and how many of those needed an index list (their environments not consecutive).
+ *   - pw_batch_bind synchronises `stream` (it reads the number of segments back); info (optional, int64 [6]) receives the number of
+ *     segments, bound environments, bound puzzles, how many of those needed an index list (their environments not consecutive), the
+ *     environments NO segment holds that launches of several steps step one lane each all the same -- 64 puzzles per wavefront, every
+ *     lane with its own copy of its puzzle's block (at most 8 movables, 1 KB) in LDS -- and the bytes of such a copy's slot.
  * Measured (one C4 shard, 65 536 environments): DESIGN.md section 4 K1g. */
 int pw_batch_bind(PwEngine* e, const int32_t* puzzle_id, int32_t batch, int64_t* info, void* stream);
 int pw_batch_unbind(PwEngine* e);

@@ -955,10 +955,11 @@ class Engine:
         one lane per environment with the puzzle's push tables in LDS, for every puzzle that at least ``bind_min_envs``
         environments of the batch play (the others keep the lane groups, in the same launch).  The ids may only change through
         ``resample`` / before a ``reset`` on this tensor (both rebuild the binding), else bind again."""
-        info = (c_int64 * 4)()
+        info = (c_int64 * 6)()
         check(lib.pw_batch_bind(self.handle, _ptr(puzzle_id), puzzle_id.shape[0], info, self._stream()))
         self._bound = puzzle_id  # (the engine keeps the pointer: the tensor must stay alive)
-        return {"segments": info[0], "bound_envs": info[1], "bound_puzzles": info[2], "listed_puzzles": info[3]}
+        # (lane_envs: environments no segment holds that launches of several steps step one lane each, 64 puzzles per wavefront)
+        return {"segments": info[0], "bound_envs": info[1], "bound_puzzles": info[2], "listed_puzzles": info[3], "lane_envs": info[4]}
 
     def unbind(self) -> None:
         check(lib.pw_batch_unbind(self.handle))

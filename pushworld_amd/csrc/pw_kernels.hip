@@ -102,8 +102,8 @@ struct PwSegDesc;
 struct PwBind {
   const int32_t* puzzle_id;  // the key: calls that pass this pointer and this batch size take the bound launches
   int32_t batch;
-  int32_t* d_ints;           // one allocation: cnt / mn / mx / seg_base / perm_base [P each], rank / perm [B each], meta [8]
-  int32_t *cnt, *mn, *mx, *seg_base, *perm_base, *rank, *perm, *meta;
+  int32_t* d_ints;           // one allocation: cnt / mn / mx / seg_base / perm_base [P each], rank / perm [B each], mlist [B][2], meta [16]
+  int32_t *cnt, *mn, *mx, *seg_base, *perm_base, *rank, *perm, *mlist, *meta;
   uint8_t* d_bound;          // [B]
   PwSegDesc* d_segs;         // [seg_cap]
   int32_t seg_cap;           // upper bound of the number of segments of any assignment: B / 256 + min(P, B / min_envs) + 1
@@ -111,6 +111,8 @@ struct PwBind {
                              // it back), seg_cap after an asynchronous re-bind (pw_resample / pw_reset on the bound buffer)
   int32_t min_envs;
   int64_t info[4];           // segments, bound environments, bound puzzles, of them with an index list (as of the last pw_batch_bind)
+  int32_t multi_envs;        // environments no segment holds that pw_step_mseg_kernel can step (-1: unknown, after an asynchronous re-bind)
+  uint32_t multi_slot;       // ... and the LDS bytes the blocks of a wavefront's 64 puzzles need at most
   uint32_t lds_bytes;        // dynamic LDS of the launches: the largest block among the bound puzzles (after an asynchronous re-bind:
                              // the largest block of the set)
 };

@@ -37,6 +37,8 @@ def _pool(kind):
         levels, n_l0 = (1,), 0
     elif kind == "levels":  # all 223 Level 1-4 puzzles (N_pad 32; `Mind The Gap` has no block: it stays with the lane groups)
         levels, n_l0 = (1, 2, 3, 4), 0
+    elif kind == "l0only":  # 700 Level-0 puzzles, a few environments each: no segment at all
+        levels, n_l0 = (), 700
     else:  # "c4": 700 Level-0 puzzles (two or three environments each: unbound) + the 223 Level 1-4 puzzles
         levels, n_l0 = (1, 2, 3, 4), 700
     if n_l0:
@@ -51,7 +53,9 @@ def _pool(kind):
 
 
 def _ids(kind, B, n, first, rng, order):
-    if kind == "c4":  # half of the environments on the Level-0 puzzles, half on the Level 1-4 ones
+    if kind == "l0only":
+        ids = rng.integers(0, n, size=B)
+    elif kind == "c4":  # half of the environments on the Level-0 puzzles, half on the Level 1-4 ones
         ids = np.concatenate([rng.integers(0, first, size=B // 2), first + (np.arange(B - B // 2) * (n - first)) // (B - B // 2)])
     else:
         ids = (np.arange(B, dtype=np.int64) * n) // B
@@ -160,9 +164,11 @@ def test_bound_steps_against_the_oracle(kind, order, B, opts):
     ("level1", "sorted", 8192, {}),
     ("levels", "shuffled", 16384, {}),
     ("levels", "sorted", 16384, {"bind_lanes": 1}),
-    ("c4", "sorted", 32768, {}),                      # (partly bound: by default the lane groups step every environment)
-    ("c4", "sorted", 32768, {"bind_rollouts": 1}),    # segments and lane groups side by side on two streams
-    ("c4", "shuffled", 32768, {"bind_rollouts": 1, "bind_fused": 2}),
+    ("c4", "sorted", 32768, {}),                      # segments + the rest one lane each, 64 puzzles per wavefront (pw_step_mseg_kernel)
+    ("c4", "shuffled", 32768, {"bind_fused": 2}),     # ... one kernel after the other on the caller's stream
+    ("c4", "sorted", 20000, {"bind_min_envs": 64}),   # partly bound AND a rest with big puzzles: the lane groups step every environment
+    ("c4", "sorted", 20000, {"bind_min_envs": 64, "bind_rollouts": 1}),  # ... or segments and lane groups side by side on two streams
+    ("l0only", "sorted", 16384, {}),                  # no segment: every environment through pw_step_mseg_kernel
 ])
 def test_bound_rollouts_against_the_oracle(kind, order, B, opts):
     """64-step launches (pw_rollout) of a bound batch with every step's history, twice in a row (the second launch starts from
@@ -182,7 +188,15 @@ def test_bound_rollouts_against_the_oracle(kind, order, B, opts):
                        engine_options=opts)
     NP = vec.num_objects_padded
     vec.reset()
-    assert vec.bound_info["bound_envs"] > B // 3
+    info = vec.bound_info
+    if kind == "l0only":
+        assert info["bound_envs"] == 0 and info["lane_envs"] == B
+    elif kind == "c4" and "bind_min_envs" not in opts:
+        assert info["bound_envs"] > B // 3 and info["bound_envs"] + info["lane_envs"] == B  # every environment is a lane
+    elif kind == "c4":
+        assert 0 < info["bound_envs"] + info["lane_envs"] < B  # (Level 1-4 puzzles below 64 environments: too big for a lane's slot)
+    else:
+        assert info["bound_envs"] > B // 3
     w, (want_d, want_r, want_te, want_tr, want_steps, want_last) = _oracle_run(texts, ids, acts, max_steps, NP)
     w_dev = torch.as_tensor(w).to(vec.device)
     acts_dev = torch.as_tensor(acts).to(vec.device)
@@ -309,5 +323,5 @@ def test_unbound_calls_keep_working_next_to_a_binding():
     assert torch.equal(a.reward.view(torch.int64), b.reward.view(torch.int64)) and a.counters() == b.counters()
     n = VecPushWorld(pz, B, puzzle_ids=ids, max_steps=25, observation=None, device=0, bind=True, engine_options={"step_tables": "none"})
     n.reset()
-    assert n.bound_info == {"segments": 0, "bound_envs": 0, "bound_puzzles": 0, "listed_puzzles": 0}
+    assert n.bound_info == {"segments": 0, "bound_envs": 0, "bound_puzzles": 0, "listed_puzzles": 0, "lane_envs": 0}
     n.step(acts[0])
