@@ -110,9 +110,11 @@ struct PwBind {
   int32_t seg_grid;          // workgroups the segment role is launched with: the exact number after pw_batch_bind (which reads
                              // it back), seg_cap after an asynchronous re-bind (pw_resample / pw_reset on the bound buffer)
   int32_t min_envs;
+  int32_t epw_log2;      // PW_OPT_BIND_SPREAD when the list was built: at most 64 >> this environments per wavefront
   int64_t info[4];           // segments, bound environments, bound puzzles, of them with an index list (as of the last pw_batch_bind)
   int32_t multi_envs;        // environments no segment holds that pw_step_mseg_kernel can step (-1: unknown, after an asynchronous re-bind)
   uint32_t multi_slot;       // ... and the LDS bytes the blocks of a wavefront's 64 puzzles need at most
+  uint32_t lds_bytes0;       // ... of the launches of one step (the blocks with wall bitmaps)
   uint32_t lds_bytes;        // dynamic LDS of the launches: the largest block among the bound puzzles (after an asynchronous re-bind:
                              // the largest block of the set)
 };
@@ -212,6 +214,7 @@ struct PwEngine {
   int bind_min_envs;       // PW_OPT_BIND_MIN_ENVS (0 = default)
   int bind_max_kb;         // PW_OPT_BIND_MAX_KB: largest block (KiB of LDS) that is bound (0 = 48)
   int bind_rollouts;       // PW_OPT_BIND_ROLLOUTS: launches of several steps take the segments: 0 when every environment is bound, 1 always, 2 never
+  int bind_spread;         // PW_OPT_BIND_SPREAD: 0 automatic, k = at most 64 >> (k - 1) environments per wavefront of the segment kernels
   int bind_lanes;          // PW_OPT_BIND_LANES: 0 automatic, k = at most 2^(k - 1) lanes per environment
   int bind_fused;          // PW_OPT_BIND_FUSED: 0 automatic, 2 never (segments and lane groups as two launches)
   uint32_t* d_bind_mismatch;  // device counter (StepArgs::bind_mismatch)

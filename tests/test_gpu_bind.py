@@ -104,6 +104,8 @@ def _oracle_run(texts, ids, acts, max_steps, NP):
     ("c4", "sorted", 20000, {"step_quad16": "never", "bind_min_envs": 32}),
     ("levels", "sorted", 16384, {"bind_lanes": 1}),   # one lane per environment whatever the puzzle
     ("levels", "shuffled", 16384, {"bind_lanes": 2}),  # at most two
+    ("levels", "shuffled", 16384, {"bind_spread": 3}),  # at most 16 environments per wavefront
+    ("c4", "sorted", 32768, {"bind_spread": 5, "bind_lanes": 1}),  # ... 4, one lane each
 ])
 def test_bound_steps_against_the_oracle(kind, order, B, opts):
     import torch
@@ -169,6 +171,9 @@ def test_bound_steps_against_the_oracle(kind, order, B, opts):
     ("c4", "sorted", 20000, {"bind_min_envs": 64}),   # partly bound AND a rest with big puzzles: the lane groups step every environment
     ("c4", "sorted", 20000, {"bind_min_envs": 64, "bind_rollouts": 1}),  # ... or segments and lane groups side by side on two streams
     ("l0only", "sorted", 16384, {}),                  # no segment: every environment through pw_step_mseg_kernel
+    ("l0only", "sorted", 16384, {"bind_spread": 3}),  # ... 16 environments per wavefront
+    ("c4", "shuffled", 32768, {"bind_spread": 4}),    # 8 environments per wavefront in both kernels
+    ("levels", "sorted", 16384, {"bind_spread": 2}),
 ])
 def test_bound_rollouts_against_the_oracle(kind, order, B, opts):
     """64-step launches (pw_rollout) of a bound batch with every step's history, twice in a row (the second launch starts from

@@ -70,7 +70,8 @@ def per_puzzle(args):
             texts.append(open(p).read())
     B = args.per_puzzle
     pset = _capi.PuzzleSet([_capi.ParsedPuzzle(t) for t in texts], 0)
-    vec = VecPushWorld(pset, B, puzzle_ids=np.zeros(B, np.int64), max_steps=100, observation=None, device=0, autoreset=True, bind=True)
+    vec = VecPushWorld(pset, B, puzzle_ids=np.zeros(B, np.int64), max_steps=100, observation=None, device=0, autoreset=True, bind=True,
+                       engine_options={"bind_spread": args.spread} if args.spread else {})
     hdr = np.frombuffer(pset.headers(), np.uint8).reshape(-1, _capi.PUZZLE_HEADER_BYTES)
     acts = torch.as_tensor(np.random.default_rng(0).integers(0, 4, size=(64, B), dtype=np.uint8)).cuda()
     rows = []
@@ -83,7 +84,7 @@ def per_puzzle(args):
     rows.sort(reverse=True)
     us = np.array([r[0] for r in rows])
     print(f"{B} environments of one puzzle, 64-step launches, us per step: median {np.median(us):.2f} p90 {np.percentile(us, 90):.2f} max {us.max():.2f}")
-    for r in rows[:25]:
+    for r in rows[:args.rows]:
         print(f"  {r[0]:7.2f} us/step  N={r[2]:2d} bound={r[3]}  {r[1]}")
     if args.json:
         with open(args.json, "w") as f:
@@ -97,6 +98,8 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--variants", default="unbound,bound,bound-split")
     ap.add_argument("--per-puzzle", type=int, default=0, help="environments of ONE Level 1-4 puzzle at a time (bound): microseconds per step of 64-step launches")
+    ap.add_argument("--rows", type=int, default=25, help="--per-puzzle: lines printed (slowest first)")
+    ap.add_argument("--spread", type=int, default=0, help="PW_OPT_BIND_SPREAD of the per-puzzle runs")
     args = ap.parse_args()
     if args.per_puzzle:
         return per_puzzle(args)
@@ -115,6 +118,9 @@ def main():
         for k in (1, 2, 3):
             if f"lanes{k}" in name:
                 opts["bind_lanes"] = k
+        for k in (1, 2, 3, 4, 5):
+            if f"spread{k}" in name:
+                opts["bind_spread"] = k
         vec = build(args.config, B, bind, opts)
         for k in range(64):
             vec.step(acts1[k])
