@@ -314,8 +314,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       the one they were bound to, since the engine was created -- 0 unless the caller changed puzzle_id
                                       behind the binding's back */
 #define PW_OPT_BIND_LANES 42         /* pw_batch_bind (read when binding): lanes per environment of the segments -- 0 automatic (1 up to 7 movables, 2 from 8,
-                                      4 from 12: a step's latency grows with the movables and a launch lasts as long as its slowest segment),
-                                      1 / 2 / 3 = at most 1 / 2 / 4 (A/B runs) */
+                                      4 from 12, 8 from 17: a step's latency grows with the movables and a launch lasts as long as its slowest
+                                      segment), 1 / 2 / 3 / 4 = at most 1 / 2 / 4 / 8 (A/B runs) */
 #define PW_OPT_BIND_ROLLOUTS 43      /* launches of several steps (pw_rollout) on a bound batch: 0 (default) the segments when EVERY environment of the batch
                                       is bound, else the lane groups for all of them (measured: next to lane groups that fill the chip the
                                       segment role does not finish sooner); 1 always (segments and lane groups side by side on two streams), 2 never */

@@ -105,6 +105,7 @@ def _oracle_run(texts, ids, acts, max_steps, NP):
     ("levels", "sorted", 16384, {"bind_lanes": 1}),   # one lane per environment whatever the puzzle
     ("levels", "shuffled", 16384, {"bind_lanes": 2}),  # at most two
     ("levels", "shuffled", 16384, {"bind_spread": 3}),  # at most 16 environments per wavefront
+    ("levels", "sorted", 16384, {"bind_lanes": 3}),    # at most four lanes: `Clean Sweep` (19 movables) two blocks of pairs per lane, not eight lanes
     ("c4", "sorted", 32768, {"bind_spread": 5, "bind_lanes": 1}),  # ... 4, one lane each
 ])
 def test_bound_steps_against_the_oracle(kind, order, B, opts):
@@ -174,6 +175,7 @@ def test_bound_steps_against_the_oracle(kind, order, B, opts):
     ("l0only", "sorted", 16384, {"bind_spread": 3}),  # ... 16 environments per wavefront
     ("c4", "shuffled", 32768, {"bind_spread": 4}),    # 8 environments per wavefront in both kernels
     ("levels", "sorted", 16384, {"bind_spread": 2}),
+    ("levels", "shuffled", 16384, {"bind_lanes": 3}),
 ])
 def test_bound_rollouts_against_the_oracle(kind, order, B, opts):
     """64-step launches (pw_rollout) of a bound batch with every step's history, twice in a row (the second launch starts from
