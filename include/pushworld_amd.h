@@ -321,10 +321,10 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       segment role does not finish sooner); 1 always (segments and lane groups side by side on two streams), 2 never */
 #define PW_OPT_BIND_MAX_KB 44        /* pw_batch_bind (read when binding): puzzles whose table block exceeds this many KiB of LDS stay with the lane groups
                                       (0 = default 48: every benchmark puzzle is bound; the launches carry as much LDS as the largest BOUND block) */
-#define PW_OPT_BIND_SPREAD 45         /* pw_batch_bind (read when binding): environments per wavefront of the segment kernels -- 0 automatic, 1 .. 5 = at most
-                                      64 / 32 / 16 / 8 / 4 (lanes per environment included): a wavefront's step lasts as long as the deepest push
-                                      chain among its environments, a launch of many steps as long as its slowest wavefront; the idle lanes'
-                                      wavefronts run on SIMDs that have room (A/B runs; results do not depend on it) */
+#define PW_OPT_BIND_SPREAD 45         /* pw_batch_bind (read when binding): environments per wavefront of the segment kernels -- 0 automatic (= 64: measured,
+                                      fewer do not help: DESIGN K1g), 1 .. 5 = at most 64 / 32 / 16 / 8 / 4 (lanes per environment included; the other
+                                      lanes idle); + 16 x (1 .. 5): the same for the listed environments of pw_step_mseg_kernel alone (else they
+                                      follow the segments' value).  A/B runs; results do not depend on it */
 #define PW_OPT_OBS_TUNE_MS 40        /* pw_obs_alloc_tuned: wall-clock budget of the candidate screen in milliseconds (0 = default 10 000): no
                                       further candidate is allocated once it is spent (the best so far is kept and tuned) -- bounds the
                                       constructor when several ranks of a node screen at the same time */

@@ -219,7 +219,7 @@ OPTIONS = {
     "bind_fused": 37,          # launches of a bound batch: 0 / "auto" one launch for segments + lane groups, 2 two launches
     "bind_max_kb": 44,         # largest table block (KiB of LDS) that is bound (0 = default 48)
     "bind_rollouts": 43,       # pw_rollout on a bound batch: 0 / "auto" segments when every environment is bound, 1 always, 2 never
-    "bind_spread": 45,         # environments per wavefront of the segment kernels: 0 automatic, 1 .. 5 = at most 64 / 32 / 16 / 8 / 4
+    "bind_spread": 45,         # environments per wavefront of the segment kernels: 0 automatic, 1 .. 5 = at most 64 / 32 / 16 / 8 / 4 (+ 16 x the same: listed lanes only)
     "bind_lanes": 42,          # lanes per environment of the segments: 0 automatic, 1 / 2 / 3 / 4 = at most 1 / 2 / 4 / 8
     "bind_puzzles": 38,        # read-only: puzzles of the set that can be bound (table block within 16 KB of LDS)
     "bind_mismatches": 39,     # read-only: environments found with another puzzle id than the one they were bound to

@@ -110,6 +110,7 @@ struct PwBind {
   int32_t seg_grid;          // workgroups the segment role is launched with: the exact number after pw_batch_bind (which reads
                              // it back), seg_cap after an asynchronous re-bind (pw_resample / pw_reset on the bound buffer)
   int32_t min_envs;
+  int32_t mepw_log2;     // ... of pw_step_mseg_kernel
   int32_t epw_log2;      // PW_OPT_BIND_SPREAD when the list was built: at most 64 >> this environments per wavefront
   int64_t info[4];           // segments, bound environments, bound puzzles, of them with an index list (as of the last pw_batch_bind)
   int32_t multi_envs;        // environments no segment holds that pw_step_mseg_kernel can step (-1: unknown, after an asynchronous re-bind)

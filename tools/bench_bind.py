@@ -121,6 +121,8 @@ def main():
         for k in (1, 2, 3, 4, 5):
             if f"spread{k}" in name:
                 opts["bind_spread"] = k
+            if f"list{k}" in name:  # the listed environments only (pw_step_mseg_kernel)
+                opts["bind_spread"] = 16 * k
         vec = build(args.config, B, bind, opts)
         for k in range(64):
             vec.step(acts1[k])
