@@ -59,7 +59,7 @@ if [ -n "$(stale C4_state C4_rollout)" ]; then
   sq c4_sq1 "$SQ1" tools/profile_kernels.py --what c4_step --steps 40 --rollouts 4
   sq c4_sq2 "$SQ2" tools/profile_kernels.py --what c4_step --steps 40 --rollouts 4
   SPECS+=("C4_state:pw_step_group_mixed_kernel<true,:65536:$P/c4_fetch_results.db:$P/c4_write_results.db"
-          "C4_rollout:pw_step_group_mixed_kernel<false,:4194304:$P/c4_fetch_results.db:$P/c4_write_results.db")
+          "C4_rollout:pw_step_seg_kernel<+pw_step_mseg_kernel<:4194304:$P/c4_fetch_results.db:$P/c4_write_results.db")  # (bound: two kernels side by side)
 fi
 if [ -n "$(stale C2_step C2_rollout)" ]; then
   prof3 c2s tools/profile_kernels.py --what c2_step --steps 200 --rollouts 0

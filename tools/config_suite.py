@@ -383,7 +383,8 @@ def run_c4(obs, key, cpu=True):
         msr = launch_ms(eng, lambda: vec.rollout(acts), 20)
         out["rollout_64_steps_per_launch"] = entry(B * T / dtr, "env-steps/s", "the same shard, pw_rollout: 64 steps per launch (state in "
                                                    "registers between the steps: per launch the state once in, once out + 64 action bytes)",
-                                                   "pw_step_group_mixed_kernel", rollout_bytes(eng.np, T), B * T, msr, "C4_rollout")
+                                                   "pw_step_seg_kernel + pw_step_mseg_kernel" if vec.bound_info else "pw_step_group_mixed_kernel",
+                                                   rollout_bytes(eng.np, T), B * T, msr, "C4_rollout")
     else:
         for _ in range(3):
             one()

@@ -5,6 +5,8 @@ read as 64 bytes on gfx950: doubled), one record per configuration of tools/conf
 
     python tools/make_kernel_pmc_record.py SOURCE  KEY:KERNEL_SUBSTRING:UNITS_PER_LAUNCH:FETCH_DB:WRITE_DB [...] > profiles/pmc_kernels_latest.json
 
+(``KERNEL_SUBSTRING`` = ``a+b``: a call that launches two kernels -- the bound C4 rollouts: segments + listed lanes -- is their sum.)
+
 ``--merge=FILE`` first: records of FILE whose kernel sources (tools/config_suite.py: KEY_SOURCES) are unchanged are kept, so a
 collection only has to re-measure what changed.  ``UNITS_PER_LAUNCH`` selects the dispatches (grid sizes differ between the single-step launches and the rollouts of one
 profiled run: only dispatches whose duration-ordered position matches are not needed -- the caller passes one database pair per
@@ -52,8 +54,14 @@ def main():
         key, kernel, units, fetch_db, write_db = parts[:5]
         grid = int(parts[5]) if len(parts) > 5 and parts[5] else None
         mult = int(parts[6]) if len(parts) > 6 and parts[6] else 1  # dispatches per call (a render in slices)
-        f = mean_counter(fetch_db, kernel, "FETCH_SIZE", grid)
-        w = mean_counter(write_db, kernel, "WRITE_SIZE", grid)
+        if "+" in kernel:  # a call that launches several kernels (once each): the sum of their per-launch means
+            fs = [mean_counter(fetch_db, k, "FETCH_SIZE", grid) for k in kernel.split("+")]
+            ws = [mean_counter(write_db, k, "WRITE_SIZE", grid) for k in kernel.split("+")]
+            f = None if any(x is None for x in fs) else (" + ".join(x[0] for x in fs), sum(x[1] for x in fs), min(x[2] for x in fs), sorted({g for x in fs for g in x[3]}))
+            w = None if any(x is None for x in ws) else (" + ".join(x[0] for x in ws), sum(x[1] for x in ws), min(x[2] for x in ws), sorted({g for x in ws for g in x[3]}))
+        else:
+            f = mean_counter(fetch_db, kernel, "FETCH_SIZE", grid)
+            w = mean_counter(write_db, kernel, "WRITE_SIZE", grid)
         if f is None or w is None:
             print(f"no dispatches of {kernel!r} (grid {grid}) in {fetch_db} / {write_db}", file=sys.stderr)
             continue
