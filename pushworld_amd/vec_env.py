@@ -59,8 +59,9 @@ class VecPushWorld:
             tuned in place.
         bind: ``pw_batch_bind`` the puzzle assignment at every ``reset`` (and behind every device-side ``resample``): puzzles played by
             at least 48 environments of the batch are stepped one lane per environment with their push tables in LDS instead of by
-            lane groups walking the tables through the caches.  Default (None): on, except for sets of 8 x 8 puzzles
-            (whole-grid boards in registers), ``incremental`` and ``resample`` (a binding is rebuilt behind every ``pw_resample``).  Same results either way.
+            lane groups walking the tables through the caches.  Default (None): on, except for ``incremental`` and ``resample`` (a
+            binding is rebuilt behind every ``pw_resample``); a set of 8 x 8 puzzles keeps its whole-grid boards unless the segments
+            hold every environment.  Same results either way.
         engine_options: ``pw_engine_set_option`` settings (``_capi.OPTIONS``), e.g. ``{"step_kernel": "lane"}`` --
             kernel selection for tests and A/B runs; results never depend on them.
     """
@@ -100,7 +101,9 @@ class VecPushWorld:
         self._obs_current = False  # the observation buffer holds the observation of self.pos
         if bind is None:
             # (not with `resample`: every step would rebuild the binding behind its pw_resample -- three small launches)
-            bind = not self.incremental and self.engine.get_option("bind_puzzles") > 0 and self.engine.get_option("step_board_set") == 0 \
+            # (sets of 8 x 8 puzzles too: the engine takes the segments where they hold EVERY environment -- C2 -- and its whole-grid
+            # boards otherwise)
+            bind = not self.incremental and self.engine.get_option("bind_puzzles") > 0 \
                 and "step_kernel" not in (engine_options or {}) and (resample is False or resample is None)
         self._bind = bool(bind)
         self.bound_info = None  # what the last pw_batch_bind reported (segments, bound environments / puzzles)

@@ -196,7 +196,7 @@ def test_configs_object_of_the_line():
     assert c1["render_plan_100_steps"]["frames"] == 101 and c1["render_plan_100_steps"]["value"] < 100.0
     c2 = cfg["C2"]
     assert c2["unit"] == "env-steps/s" and c2["units_per_launch"] == 4096 and c2["algorithmic_bytes_per_unit"] == 38
-    assert c2["kernel"] == "pw_step_board_kernel" and 0 < c2["frac"] < 1 and c2["launches_timed"] == 500
+    assert c2["kernel"] == "pw_step_seg_kernel" and 0 < c2["frac"] < 1 and c2["launches_timed"] == 500  # (every environment bound)
     assert c2["rollout_64_steps_per_launch"]["value"] > c2["value"]
     assert c2["counters"]["env_steps"] > 0 and c2["counters"]["episodes_ended"] > 0
     c5 = cfg["C5_2_obstacle"]

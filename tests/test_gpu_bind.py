@@ -332,3 +332,52 @@ def test_unbound_calls_keep_working_next_to_a_binding():
     n.reset()
     assert n.bound_info == {"segments": 0, "bound_envs": 0, "bound_puzzles": 0, "listed_puzzles": 0, "lane_envs": 0}
     n.step(acts[0])
+
+
+@pytest.mark.parametrize("full", [True, False])
+def test_sets_of_8x8_puzzles_segments_when_every_environment_is_bound(full):
+    """A set whose puzzles all fit 8 x 8 (the whole-grid board kernel's sets; C2 is one): a bound batch takes the segments when they hold
+    EVERY environment and keeps the boards otherwise (a puzzle below the threshold) -- single steps and 64-step launches against the
+    oracle either way."""
+    import torch
+
+    from pushworld_amd import _capi
+    from pushworld_amd import benchmark_data as bd
+    from pushworld_amd.vec_env import VecPushWorld
+
+    texts = []
+    for t in bd.level0_texts(limit=60).values():
+        rows = [ln.split() for ln in t.strip().splitlines()]
+        if len(rows) <= 6 and max(len(r) for r in rows) <= 6:  # (8 x 8 with the border)
+            texts.append(t)
+    texts = texts[:12]
+    assert len(texts) >= 6
+    B, T, max_steps = 4096, 96, 40
+    rng = np.random.default_rng(3)
+    ids = (np.arange(B, dtype=np.int64) * len(texts)) // B
+    if not full:  # the last puzzle keeps 25 environments: below the threshold of 48, not bound
+        ids[np.nonzero(ids == len(texts) - 1)[0][25:]] = 1
+    acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
+    pset = _capi.PuzzleSet([_capi.ParsedPuzzle(t) for t in texts], 0)
+    vec = VecPushWorld(pset, B, puzzle_ids=ids, max_steps=max_steps, observation=None, device=0, autoreset=True)  # (bind: the default)
+    assert vec.engine.get_option("step_board_set") == 1
+    NP = vec.num_objects_padded
+    vec.reset()
+    info = vec.bound_info
+    assert info is not None and (info["bound_envs"] == B if full else 0 < info["bound_envs"] < B), info
+    w, (want_d, want_r, want_te, want_tr, want_steps, want_last) = _oracle_run(texts, ids, acts, max_steps, NP)
+    w_dev = torch.as_tensor(w).to(vec.device)
+    acts_dev = torch.as_tensor(acts).to(vec.device)
+    for t in range(32):
+        _, r, te, tr = vec.step(acts_dev[t])
+        d = (vec.pos.view(B, NP * 2).to(torch.int64) * w_dev).sum(dim=1).cpu().numpy()
+        assert (d == want_d[t]).all(), t
+        assert (r.cpu().numpy().view(np.uint64) == want_r[t].view(np.uint64)).all(), t
+        assert (te.cpu().numpy() == want_te[t]).all() and (tr.cpu().numpy() == want_tr[t]).all(), t
+    r, te, tr = vec.rollout(acts_dev[32:].contiguous(), history=True)
+    assert (r.cpu().numpy().view(np.uint64) == want_r[32:].view(np.uint64)).all()
+    assert (te.cpu().numpy() == want_te[32:]).all() and (tr.cpu().numpy() == want_tr[32:]).all()
+    assert (vec.states() == want_last).all()
+    assert (vec.steps.cpu().numpy() == want_steps[T - 1]).all()
+    c = vec.counters()
+    assert c["env_steps"] == B * T and c["episodes_ended"] == int(((want_te | want_tr) != 0).sum())

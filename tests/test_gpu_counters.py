@@ -54,7 +54,8 @@ def test_counters_equal_the_oracle_trace(golden, flavour):
             "rollout": {"step_boards": "never"}, "rollout-lane": {"step_kernel": "lane"}}.get(flavour, {})
     obs = "uint8" if flavour in ("render", "fused", "delta") else None
     vec = VecPushWorld(pool, B, puzzle_ids=ids, max_steps=max_steps, pixels_per_cell=3, border_width=1, observation=obs,
-                       autoreset=True, incremental=flavour == "delta", engine_options=opts)
+                       autoreset=True, incremental=flavour == "delta", engine_options=opts,
+                       bind=False if flavour == "boards" else None)  # ("boards-rollout": every environment bound -- the segments)
     if flavour == "fused":
         vec.engine.set_option("fused_step_render", 1)
     if flavour.startswith("boards"):

@@ -22,7 +22,10 @@ def build(config, B, bind, opts):
     from pushworld_amd.sharding import c4_global_puzzle_ids, shard_puzzle_ids
     from pushworld_amd.vec_env import VecPushWorld
 
-    if config == "c3":
+    if config == "c2":  # 4 096 (or --batch) copies of one Level-0 puzzle (BASELINE config 2)
+        texts = [next(iter(bd.level0_texts(("base",), "train", 1).values()))]
+        ids = np.zeros(B, dtype=np.int64)
+    elif config == "c3":
         texts = [open(p).read() for p in bd.level_paths(1)]
         ids = (np.arange(B, dtype=np.int64) * len(texts)) // B
     else:
@@ -111,6 +114,8 @@ def main():
     for name in args.variants.split(","):
         bind = name.startswith("bound")
         opts = {"bind_fused": 2} if name == "bound-split" else {}
+        if "noboards" in name:  # sets of 8 x 8 puzzles: not the whole-grid board kernel
+            opts["step_boards"] = "never"
         if name.endswith("-noquad"):
             opts["step_quad16"] = "never"
         if "kb16" in name:

@@ -64,8 +64,8 @@ fi
 if [ -n "$(stale C2_step C2_rollout)" ]; then
   prof3 c2s tools/profile_kernels.py --what c2_step --steps 200 --rollouts 0
   prof3 c2r tools/profile_kernels.py --what c2_step --steps 0 --rollouts 20
-  SPECS+=("C2_step:pw_step_board_kernel:4096:$P/c2s_fetch_results.db:$P/c2s_write_results.db"
-          "C2_rollout:pw_step_board_kernel:262144:$P/c2r_fetch_results.db:$P/c2r_write_results.db")
+  SPECS+=("C2_step:pw_step_seg_kernel<:4096:$P/c2s_fetch_results.db:$P/c2s_write_results.db"  # (bound: every environment in a segment)
+          "C2_rollout:pw_step_seg_kernel<:262144:$P/c2r_fetch_results.db:$P/c2r_write_results.db")
 fi
 if [ -n "$(stale C5_2_obstacle C5_pull_dont_push C5_four_pistons)" ]; then
   prof3 x2ob tools/profile_kernels.py --what expand --puzzle "level1/2 Obstacle.pwp" --steps 12

@@ -252,7 +252,9 @@ def run_c2(cpu=True):
 
     dt = wall(one, 4000, 100)
     ms = launch_ms(vec.engine, one, 500)
-    kern = "pw_step_board_kernel" if vec.engine.get_option("step_board_set") else "pw_step_group_kernel"
+    # (4 096 copies of one puzzle: every environment sits in a segment of the bound batch -- the segments, not the whole-grid boards)
+    all_bound = bool(vec.bound_info) and vec.bound_info["bound_envs"] == B
+    kern = "pw_step_seg_kernel" if all_bound else ("pw_step_board_kernel" if vec.engine.get_option("step_board_set") else "pw_step_group_kernel")
     sb = state_bytes(vec.engine.np)
     out = entry(B / dt, "env-steps/s", f"C2: 4 096 copies of {member}, state only, max_steps 100, next-step autoreset, one step per launch",
                 kern, sb, B, ms, "C2_step", ms_per_step=1e3 * dt,

@@ -5,7 +5,7 @@
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -o name -- python tools/profile_kernels.py --what expand --puzzle "level4/Four Pistons.pwp"
 
   c4_step   rank 0's shard of config C4, state only: `--steps` single-step launches (pw_step_group_mixed_kernel) and 4 rollouts
-  c2_step   config C2: 4 096 copies of one Level-0 puzzle, state only (pw_step_board_kernel)
+  c2_step   config C2: 4 096 copies of one Level-0 puzzle, state only (bound: pw_step_seg_kernel)
   expand    pw_expand4 on the first `--states` states of a breadth-first search of `--puzzle` (repeated when the state space
             is smaller), `--steps` launches cycling through buffer sets beyond the Infinity Cache
   search    the GPU breadth-first search of `--puzzle` up to `--states` states (pw_search_* kernels)
