@@ -301,9 +301,12 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
 #define PW_OPT_STEP_QUAD16_PUZZLES 32 /* read-only: puzzles of the set with such a record */
 #define PW_OPT_MAILBOX_MODE 35       /* pw_mailbox_open (A/B runs): bits 0-1 who reads the host's word across the link -- 0 every wavefront, 1 one
                                       wavefront per workgroup, 2 one wavefront of the first workgroup, which passes it on through device
-                                      memory, 3 (default) a workgroup of its own that does nothing else and runs ahead of the stepping
-                                      ones; bit 2 (+4): system-scope fences around a step instead of system-scope accesses.  Same results
-                                      (C2 round trip 38 / 10.8 / 6.2 / 6.0 us: profiles/r05_mailbox.json). */
+                                      memory, 3 a workgroup of its own that does nothing else and runs ahead of the stepping
+                                      ones; bit 2 (+4): system-scope fences around a step instead of system-scope accesses; 11 (default, round 6) =
+                                      3 pipelined: the relay wavefront reads all the slots of the ring in one trip, a stepping wavefront asks
+                                      for the next step's word before it steps and for its actions together with this step's stores, and looks
+                                      at its arrive count a step later while further steps are posted.  Same results (C2 round trip 38 / 10.8 /
+                                      6.2 / 6.0 us: profiles/r05_mailbox.json; 11: profiles/r06_mailbox.json). */
 #define PW_OPT_BIND_MIN_ENVS 36      /* pw_batch_bind: a puzzle is bound when at least this many environments of the batch play it (0 = default 48) */
 #define PW_OPT_BIND_FUSED 37         /* launches of a partly bound batch: 0 (default) single steps run segments and lane groups in ONE launch (where the
                                       per-workgroup lane-group kernel applies), launches of several steps as two kernels side by side on two

@@ -56,13 +56,14 @@ def _same_state(a, b):
 
 
 @pytest.mark.parametrize("B,host_actions,mode", [(4096, True, 2), (4096, False, 2), (1000, True, 2), (37, False, 2), (20000, True, 2),
-                                                  (4096, True, 0), (3000, False, 1), (4096, False, 6), (700, True, 4), (5000, True, 5), (4096, True, 3), (2500, False, 3), (4096, False, 7)])
+                                                  (4096, True, 0), (3000, False, 1), (4096, False, 6), (700, True, 4), (5000, True, 5), (4096, True, 3), (2500, False, 3), (4096, False, 7),
+                                                  (4096, True, 11), (4096, False, 11), (333, False, 11)])
 def test_mailbox_steps_equal_pw_step(B, host_actions, mode):
     import torch
 
     T = 160
     a, b = _twins(B, 23, max_steps=25)
-    assert a.engine.get_option("mailbox_mode") == 3
+    assert a.engine.get_option("mailbox_mode") == 11  # (3 pipelined: the default since round 6)
     a.engine.set_option("mailbox_mode", mode)  # who polls the host's word, fences or system-scope accesses: same results
     rng = np.random.default_rng(B)
     acts = rng.integers(0, 4, size=(T, B), dtype=np.uint8)
