@@ -305,7 +305,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       ones; bit 2 (+4): system-scope fences around a step instead of system-scope accesses; 11 (default, round 6) =
                                       3 pipelined: the relay wavefront reads all the slots of the ring in one trip, a stepping wavefront asks
                                       for the next step's word before it steps and for its actions together with this step's stores, and looks
-                                      at its arrive count a step later while further steps are posted.  Same results (C2 round trip 38 / 10.8 /
+                                      at its arrive count a step later while further steps are posted; bit 4 (+16): wavefront 0 keeps the per-phase clock that
+                                      pw_mailbox_close_profile returns (off by default: its clock reads made wavefront 0 the slowest of the launch).  Same results (C2 round trip 38 / 10.8 /
                                       6.2 / 6.0 us: profiles/r05_mailbox.json; 11: profiles/r06_mailbox.json). */
 #define PW_OPT_BIND_MIN_ENVS 36      /* pw_batch_bind: a puzzle is bound when at least this many environments of the batch play it (0 = default 48) */
 #define PW_OPT_BIND_FUSED 37         /* launches of a partly bound batch: 0 (default) single steps run segments and lane groups in ONE launch (where the
@@ -539,7 +540,7 @@ int pw_mailbox_run(PwMailbox* m, const uint8_t* actions, int32_t num_steps, int3
                    uint64_t* last_seq);
 /* pw_mailbox_close_profile: as the close, and (profile: int64 [8], or NULL) [0] steps completed, [1] how the kernel ended (2 stop
  * word, 3 idle limit), [2..6] ticks of the device's constant clock that wavefront 0 spent waiting for the word / reading its
- * actions / stepping / storing / counting itself in, [7] that clock's kHz. */
+ * actions / stepping / storing / counting itself in (zeros unless PW_OPT_MAILBOX_MODE has bit 4 set), [7] that clock's kHz. */
 int pw_mailbox_close_profile(PwMailbox* m, int64_t* profile);
 int pw_mailbox_close(PwMailbox* m);
 

@@ -211,7 +211,7 @@ OPTIONS = {
     "search_keys": 33,         # closed set of the searches created afterwards: 0 / "fingerprint" (default), 1 / "exact" 63-bit keys where they fit
     "expand_pair_dims": 34,    # pw_expand4 (tables in LDS): 0 / "auto" pair tables sized per pair where the uniform ones exceed 16 KB, 2 / "never"
     "step_quad16_puzzles": 32, # read-only: puzzles of the set that fit
-    "mailbox_mode": 35,        # pw_mailbox_open: 0 / 1 / 2 who polls the host's word (every wavefront / one per workgroup / one), + 4 fences
+    "mailbox_mode": 35,        # pw_mailbox_open: 0 / 1 / 2 / 3 who polls the host's word, + 4 fences, 11 = 3 pipelined (default), + 16 per-phase clock
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
     "obs_tune_ms": 40,         # pw_obs_alloc_tuned: wall-clock budget of the candidate screen (0 = default 10 000 ms)
     "obs_screen_ms": 41,       # read-only: what the last screen took
@@ -593,7 +593,8 @@ class Mailbox:
 
     def close(self, profile: bool = False):
         """Ends the kernel.  ``profile=True``: returns microseconds per step that wavefront 0 spent waiting for the host's word,
-        reading its actions, stepping, storing, and counting itself in (``pw_mailbox_close_profile``)."""
+        reading its actions, stepping, storing, and counting itself in (``pw_mailbox_close_profile``; the engine option
+        ``mailbox_mode`` needs bit 4 (+16) set before the mailbox is opened: the clock is off by default)."""
         if self.handle is None:
             return None
         handle, self.handle = self.handle, None

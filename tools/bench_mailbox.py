@@ -100,11 +100,27 @@ def main():
         for t in range(n_py):
             mb.step(acts[t])
         out[tag + "mailbox_python_step"] = (time.perf_counter() - t0) / n_py * 1e6
-        out[tag + "wavefront0_profile"] = mb.close(profile=True)
-        # ... and the synchronous cadence alone (the profile of a host that waits for every step)
+        mb.close()
+        # the per-phase clock of wavefront 0 (mode bit 4: it slows that wavefront, hence every step -- its own runs)
+        vec.engine.set_option("mailbox_mode", mode | 16)
+        # ... the synchronous cadence (the profile of a host that waits for every step)
         mb = vec.mailbox(ring=8)
         mb.run(acts_dev, 1)
         out[tag + "wavefront0_profile_sync_dev"] = mb.close(profile=True)
+        # ... and eight steps in flight alone
+        mb = vec.mailbox(ring=8)
+        mb.run(acts_dev, 8)
+        out[tag + "wavefront0_profile_ahead8_dev"] = mb.close(profile=True)
+        vec.engine.set_option("mailbox_mode", mode)
+        mb = vec.mailbox(ring=32)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            mb.run(acts_dev, 24)
+            dt = (time.perf_counter() - t0) / T * 1e6
+            best = dt if best is None else min(best, dt)
+        out[tag + "mailbox_ring32_ahead24_dev"] = best
+        mb.close()
     for k in list(out):
         if isinstance(out[k], float):
             out[k] = round(out[k], 3)
