@@ -329,6 +329,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       fewer do not help: DESIGN K1g), 1 .. 5 = at most 64 / 32 / 16 / 8 / 4 (lanes per environment included; the other
                                       lanes idle); + 16 x (1 .. 5): the same for the listed environments of pw_step_mseg_kernel alone (else they
                                       follow the segments' value).  A/B runs; results do not depend on it */
+#define PW_OPT_STEP_ONE_FUSED 46     /* pw_step_render_delta on a batch of ONE with a completion word (pw_engine_set_step_signal; frames of at least 64 KiB,
+                                      engines other than uint8 / ppc 3): 1 (default) one launch -- workgroup 0 steps and hands positions + changed rows to
+                                      the other seven through device memory --, 0 the step kernel and the redraw as two launches (rounds 4-5). */
 #define PW_OPT_OBS_TUNE_MS 40        /* pw_obs_alloc_tuned: wall-clock budget of the candidate screen in milliseconds (0 = default 10 000): no
                                       further candidate is allocated once it is spent (the best so far is kept and tuned) -- bounds the
                                       constructor when several ranks of a node screen at the same time */
@@ -563,7 +566,8 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
  * by the objects that moved are written (none for a blocked move; the whole image for environments
  * reset by PW_STEP_AUTORESET, which also covers a puzzle_id changed by pw_resample).  uint8 /
  * pixels_per_cell 3 engines; any other engine silently takes the pw_step_render path.
- * Returns PW_OK, or 1 when the launch will also write the engine's completion word (below). */
+ * Returns PW_OK, or 1 / 2 when the launch will also write the engine's completion word (below) -- 2: the step and the redraw were ONE
+ * launch (PW_OPT_STEP_ONE_FUSED) whose hand-over word carries a launch number: such a call must not be captured into a graph and replayed. */
 int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
                          int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
                          uint8_t* truncated, void* obs, int64_t env_stride_bytes, int32_t batch,

@@ -194,11 +194,14 @@ class SingleEnvCore:
         if self._graphs:
             observation, raw = self._graph_step(action)
         else:
-            signalled = self._step_call(self._acts_ptr + action) == 1
+            rc = self._step_call(self._acts_ptr + action)
+            signalled = rc >= 1
             if signalled:
                 self._signalled += 1
             observation, raw = self._read_back(signalled)
             self._eager_steps += 1
+            if rc == 2:
+                self._graphs = False  # step + redraw are ONE launch already (PW_OPT_STEP_ONE_FUSED): cheaper than a graph replay, and not replayable
             if self._graphs is None and signalled and self._eager_steps >= 8:
                 self._capture_graphs()
         self._steps += 1

@@ -315,3 +315,51 @@ def test_reset_and_errors(flavour):
     for seed in (0, 7, 123):
         _reset(flavour, pool, seed=seed)
         assert pool.current_puzzle.file_path == random.Random(seed).choice(files)
+
+
+# ----------------------------------------------------------------------- the adapters' step as one launch (round 6)
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("level1", [False, True])
+def test_single_env_step_one_launch_against_the_oracle(fused, level1, tmp_path):
+    """gym_env.py:188-226 through pw_step_render_delta on a batch of one: with PW_OPT_STEP_ONE_FUSED (default) the step and the
+    redraw of the rows it changed are ONE launch (workgroup 0 steps, seven more draw), without it two launches / a graph replay.
+    EVERY step's observation, state, reward and flags against the oracle -- an incremental redraw that misses a row shows up the
+    step it happens -- on the C1 puzzle and on a Level-1 puzzle with pushes and transitive pushes, resets included."""
+    import glob
+
+    from oracle import pw_oracle
+    from pushworld_amd import benchmark_data as bd
+    from pushworld_amd.config import BENCHMARK_PUZZLES_PATH
+    from pushworld_amd.gym_env import PushWorldEnv
+
+    if level1:
+        src = sorted(glob.glob(os.path.join(BENCHMARK_PUZZLES_PATH, "level1", "*.pwp")))[7]
+        text = open(src).read()
+    else:
+        text = next(iter(bd.level0_texts(("base",), "train", 1).values()))
+    f = tmp_path / "one.pwp"
+    f.write_text(text)
+    env = PushWorldEnv(str(f), max_steps=40)
+    assert env._engine.get_option("step_one_fused") == 1
+    env._engine.set_option("step_one_fused", fused)
+    oz = pw_oracle.OraclePuzzle(text)
+    oenv = pw_oracle.OracleEnv(oz, max_steps=40)
+    rng = np.random.default_rng(5 + fused)
+    obs, info = env.reset(seed=0)
+    ostate = oenv.reset()
+    assert info["puzzle_state"] == ostate and (obs == oz.observation(ostate, oz.height, oz.width)).all()
+    held = obs  # (a returned observation is the caller's: later steps must not change it)
+    held_copy = obs.copy()
+    for t in range(260 if level1 else 400):
+        a = int(rng.integers(0, 4)) if t % 7 else 1  # (runs against walls too: steps that change nothing)
+        obs, r, term, trunc, info = env.step(a)
+        ostate, orew, oterm, otrunc = oenv.step(a)
+        assert info["puzzle_state"] == ostate and r == orew and term == oterm and trunc == otrunc, t
+        assert (obs == oz.observation(ostate, oz.height, oz.width)).all(), t
+        if term or trunc:
+            obs, info = env.reset()
+            ostate = oenv.reset()
+            assert (obs == oz.observation(ostate, oz.height, oz.width)).all(), t
+    assert (held == held_copy).all()
+    if fused:
+        assert env._graphs is False  # (one launch per step: no graph is captured -- its hand-over word carries a launch number)
