@@ -25,21 +25,37 @@ for a in acts[:3000]:
     if te or tr:
         env.reset()
 print("gym step (+ resets)    %.2f us" % ((pc() - t0) / 3000 * 1e6), "obs", env._obs_np.shape, env._obs_np.nbytes, "bytes; graphs:", bool(env._graphs))
-T = dict(replay=0.0, wait=0.0, cold=0.0, warm=0.0)
-word = env._signal_np
-n = 3000
-for a in acts[:n]:
-    a = int(a)
-    t0 = pc()
-    word[0] = 0
-    env._graphs[a].replay()
-    t1 = pc()
-    while word[0] == 0:
-        pass
-    t2 = pc()
-    o = env._obs_np.copy()
-    t3 = pc()
-    o2 = env._obs_np.copy()
-    t4 = pc()
-    T["replay"] += t1 - t0; T["wait"] += t2 - t1; T["cold"] += t3 - t2; T["warm"] += t4 - t3
-print({k: round(v / n * 1e6, 2) for k, v in T.items()}, "us")
+def parts(label):
+    T = dict(launch=0.0, wait=0.0, cold=0.0)
+    word = env._signal_np
+    n = 3000
+    for a in acts[:n]:
+        a = int(a)
+        t0 = pc()
+        if env._graphs:
+            word[0] = 0
+            env._graphs[a].replay()
+            t1 = pc()
+            while word[0] == 0:
+                pass
+        else:
+            rc = env._step_call(env._acts_ptr + a)
+            env._signalled += 1
+            want = env._signalled
+            t1 = pc()
+            while word[0] < want:
+                pass
+        t2 = pc()
+        o = env._obs_np.copy()
+        t3 = pc()
+        T["launch"] += t1 - t0; T["wait"] += t2 - t1; T["cold"] += t3 - t2
+    print(label, {k: round(v / n * 1e6, 2) for k, v in T.items()}, "us")
+
+parts("as built (fused=%d, graphs=%s)" % (env._engine.get_option("step_one_fused"), bool(env._graphs)))
+env._engine.set_option("step_one_fused", 0)
+env._graphs = False
+parts("two launches, eager")
+env._graphs = None
+for a in acts[:50]:
+    env.step(int(a))
+parts("two launches, graphs=%s" % bool(env._graphs))
