@@ -304,8 +304,9 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       memory, 3 a workgroup of its own that does nothing else and runs ahead of the stepping
                                       ones; bit 2 (+4): system-scope fences around a step instead of system-scope accesses; 11 (default, round 6) =
                                       3 pipelined: the relay wavefront reads all the slots of the ring in one trip, a stepping wavefront asks
-                                      for the next step's word before it steps and for its actions together with this step's stores, and looks
-                                      at its arrive count a step later while further steps are posted; bit 4 (+16): wavefront 0 keeps the per-phase clock that
+                                      for the word two steps ahead and the next step's actions before it steps, waits ONCE after the step (for them and for the
+                                      previous step's stores), writes the number of steps it has completed into a word of its own -- a publisher workgroup
+                                      publishes the smallest as done: no arrive counter -- and issues this step's stores without waiting for them; bit 4 (+16): wavefront 0 keeps the per-phase clock that
                                       pw_mailbox_close_profile returns (off by default: its clock reads made wavefront 0 the slowest of the launch).  Same results (C2 round trip 38 / 10.8 /
                                       6.2 / 6.0 us: profiles/r05_mailbox.json; 11: profiles/r06_mailbox.json). */
 #define PW_OPT_BIND_MIN_ENVS 36      /* pw_batch_bind: a puzzle is bound when at least this many environments of the batch play it (0 = default 48) */
@@ -512,7 +513,8 @@ int pw_batch_unbind(PwEngine* e);
  *     launches for them, the others one lane per environment over their overlap tables / row bitboards (pw_step_lane_kernel's step);
  *   - puzzle_id is read once, at the open: episodes restart (PW_STEP_AUTORESET) on the same puzzle;
  *   - everything queued on other streams for the arrays must be complete before the open, and while the mailbox is open the
- *     engine's other stepping calls fail (the environments live in the resident kernel); pw_counters is current after the close;
+ *     engine's other stepping calls fail (the environments live in the resident kernel); pw_counters is current after the close
+ *     (the kernel adds its sums when it has to wait for a word, every 256 steps and at its end);
  *   - `actions`: device memory, or host memory (actions_on_host != 0: copied into a pinned staging slot, read by the kernel
  *     across the link);
  *   - the kernel ends by pw_mailbox_close, or BY ITSELF after idle_ms (0 = 1 000) without a post: a resident kernel would
@@ -524,8 +526,9 @@ int pw_batch_unbind(PwEngine* e);
  *     synchronisation while a mailbox is open (hipDeviceSynchronize, a hipFree / hipMalloc of another allocator on the device,
  *     pw_obs_free, destroying another engine) stalls until the kernel idles out, i.e. up to idle_ms, and ends the mailbox.
  *   - one host thread at a time per mailbox (post / wait / step / run / close are not synchronised against each other).
- * Measured (C2, 4 096 environments, tools/bench_mailbox.py, profiles/r05_mailbox.json): 6.1 us per synchronous step against 17.8 us
- * for pw_step + a stream synchronisation; 3.2 us with 8 steps in flight.  DESIGN.md K1f. */
+ * Measured (C2, 4 096 environments, tools/bench_mailbox.py, profiles/r06_mailbox.json): 6.1 - 6.6 us per synchronous step against
+ * 17.8 us for pw_step + a stream synchronisation; 1.95 us with 8 steps in flight (2.1e9 env-steps/s; 3.2 - 3.45 us before round 6).
+ * DESIGN.md K1f. */
 typedef struct PwMailbox PwMailbox;
 int pw_mailbox_open(PwEngine* e, const int32_t* puzzle_id, int8_t* pos, int32_t* steps, double* reward, int8_t* dgoals,
                     uint8_t* terminated, uint8_t* truncated, int32_t batch, uint32_t flags, int32_t ring /* 0 = 8 */,
