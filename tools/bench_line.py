@@ -86,6 +86,8 @@ def compact_sub(e):
     mb = e.get("mailbox_step")
     if isinstance(mb, dict) and "value" in mb:
         out["mailbox"] = {k: mb[k] for k in ("value", "us_per_step") if mb.get(k) is not None}
+        if mb.get("us_per_step_8_in_flight") is not None:  # (the host posts ahead of its waits: the resident kernel's own rate)
+            out["mailbox"]["us8"] = round(float(mb["us_per_step_8_in_flight"]), 3)
     return out
 
 
