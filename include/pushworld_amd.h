@@ -332,7 +332,8 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       follow the segments' value).  A/B runs; results do not depend on it */
 #define PW_OPT_STEP_ONE_FUSED 46     /* pw_step_render_delta on a batch of ONE with a completion word (pw_engine_set_step_signal; frames of at least 64 KiB,
                                       engines other than uint8 / ppc 3): 1 (default) one launch -- workgroup 0 steps and hands positions + changed rows to
-                                      the other seven through device memory --, 0 the step kernel and the redraw as two launches (rounds 4-5). */
+                                      the other seven through device memory, and of the changed rows only the changed COLUMNS are written --, 2 one launch writing
+                                      whole rows, 0 the step kernel and the redraw as two launches (rounds 4-5).  A/B runs: same observations. */
 #define PW_OPT_OBS_TUNE_MS 40        /* pw_obs_alloc_tuned: wall-clock budget of the candidate screen in milliseconds (0 = default 10 000): no
                                       further candidate is allocated once it is spent (the best so far is kept and tuned) -- bounds the
                                       constructor when several ranks of a node screen at the same time */

@@ -1,6 +1,8 @@
 """pw_step_render_delta (incremental observation maintenance) against the full render: every byte of
 the observation buffer, every step, under autoreset, puzzle re-sampling, illegal overlapping
 states, several frames.  The full render itself is pinned to the reference in test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -180,9 +182,11 @@ def test_incremental_full_size_is_a_pure_function_of_the_state():
 @pytest.mark.parametrize("kw", [dict(observation="float32", pixels_per_cell=20, border_width=2),   # the gym default: 8 workgroups
                                 dict(observation="uint8", pixels_per_cell=8, border_width=2),      # a small frame: one workgroup
                                 dict(observation="float32", pixels_per_cell=5, border_width=1)])
-def test_batch_of_one_completion_word_and_split_redraw(golden, kw):
+@pytest.mark.parametrize("fused", [1, 2, 0])  # PW_OPT_STEP_ONE_FUSED: one launch writing the changed columns / whole rows, two launches
+def test_batch_of_one_completion_word_and_split_redraw(golden, kw, fused):
     """pw_step_render_delta on a batch of ONE (what the gym / dm_env adapters launch): the changed rows leave through eight
-    workgroups where the frame has >= 64 KB, the call returns 1 and the last workgroup writes the call's number into the engine's
+    workgroups where the frame has >= 64 KB (since round 6 in the same launch as the step: the call returns 2, and only the changed
+    COLUMNS of those rows are written), the call returns 1 / 2 and the last workgroup writes the call's number into the engine's
     completion word (pw_engine_set_step_signal) after everything else -- polled here WITHOUT a stream synchronisation; the buffer
     equals the full render's every step, through autoresets (whole-frame redraws) and blocked moves (nothing to redraw)."""
     import time
@@ -196,6 +200,8 @@ def test_batch_of_one_completion_word_and_split_redraw(golden, kw):
         common = dict(max_steps=14, autoreset=True, **kw)
         full = VecPushWorld(pool, 1, **common)
         inc = VecPushWorld(pool, 1, incremental=True, **common)
+        assert inc.engine.get_option("step_one_fused") == 1
+        inc.engine.set_option("step_one_fused", fused)
         word = torch.zeros((1,), dtype=torch.int64).pin_memory()
         inc.engine.set_step_signal(word)
         assert torch.equal(full.reset(), inc.reset())
@@ -206,7 +212,9 @@ def test_batch_of_one_completion_word_and_split_redraw(golden, kw):
             a = torch.randint(0, 4, (1,), dtype=torch.uint8, device=full.device, generator=g)
             torch.cuda.synchronize()  # (the action is there; nothing below waits for the stream)
             rc = inc._call_step_delta(a.data_ptr())
-            assert rc == 1, (key, t)  # the generic kernel redraws: the word will be written
+            # the word will be written -- by the redraw kernel behind the step kernel (1), or by the ONE launch that does both (2:
+            # round 6, frames of at least 64 KiB -- state in device memory, autoresets and blocked moves included)
+            assert rc == (2 if fused and int(inc.engine.obs_bytes) >= (64 << 10) else 1), (key, t, rc)
             signalled += 1
             t0 = time.time()
             while int(word[0]) != signalled:
