@@ -151,6 +151,30 @@ def test_soak_slots_come_round(ring, ahead, host):
     assert a.counters() == b.counters()
 
 
+@pytest.mark.parametrize("B,ahead", [(65536, 8), (65536 - 100, 1), (40000, 3)])
+def test_largest_batches_in_flight(B, ahead):
+    """The most environments a mailbox takes (65 536 = 1 024 stepping wavefronts + the relay and the publisher workgroup, all resident):
+    every wavefront's own step count, the publisher's look over all of them, posts ahead of the waits -- the state, the counters and the
+    last verdicts after 1 500 steps equal pw_rollout's on a twin."""
+    import torch
+
+    T = 1500
+    a, b = _twins(B, 29, max_steps=30)
+    acts = np.random.default_rng(B + ahead).integers(0, 4, size=(T, B), dtype=np.uint8)
+    acts_dev = torch.as_tensor(acts).to(a.device)
+    torch.cuda.synchronize()
+    for k in range(0, T, 500):
+        b.rollout(acts_dev[k:k + 500])
+    with a.mailbox(ring=8) as mb:
+        last = mb.run(acts_dev, ahead)
+        assert last == T
+        r, te, tr = mb.wait(last)
+        assert (r.view(np.uint64) == b.reward.cpu().numpy().view(np.uint64)).all()
+        assert (te == b.terminated.cpu().numpy()).all() and (tr == b.truncated.cpu().numpy()).all()
+    _same_state(a, b)
+    assert a.counters() == b.counters()
+
+
 def test_idle_limit_ends_the_kernel():
     import torch
 
