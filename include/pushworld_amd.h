@@ -334,6 +334,11 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       engines other than uint8 / ppc 3): 1 (default) one launch -- workgroup 0 steps and hands positions + changed rows to
                                       the other seven through device memory, and of the changed rows only the changed COLUMNS are written --, 2 one launch writing
                                       whole rows, 0 the step kernel and the redraw as two launches (rounds 4-5).  A/B runs: same observations. */
+#define PW_OPT_MAILBOX_SEG 47        /* pw_mailbox_open on a BOUND batch (pw_batch_bind) whose every environment sits in a segment, pipelined mode: 0 (default)
+                                      the resident kernel runs the segments -- the puzzle's tables copied into LDS once, at the open --, 2 never (one lane
+                                      per environment over the tables in memory).  Same results. */
+#define PW_OPT_MAILBOX_FORM 48       /* read-only: 0 no mailbox open, 1 its kernel steps one lane per environment (whole-grid boards / tables in memory), 2 the segments
+                                      of the bound batch */
 #define PW_OPT_OBS_TUNE_MS 40        /* pw_obs_alloc_tuned: wall-clock budget of the candidate screen in milliseconds (0 = default 10 000): no
                                       further candidate is allocated once it is spent (the best so far is kept and tuned) -- bounds the
                                       constructor when several ranks of a node screen at the same time */

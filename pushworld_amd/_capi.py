@@ -215,6 +215,8 @@ OPTIONS = {
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
     "obs_tune_ms": 40,         # pw_obs_alloc_tuned: wall-clock budget of the candidate screen (0 = default 10 000 ms)
     "obs_screen_ms": 41,       # read-only: what the last screen took
+    "mailbox_form": 48,        # read-only: 0 no mailbox open, 1 lanes / boards, 2 the segments of the bound batch
+    "mailbox_seg": 47,         # the resident kernel of a fully bound batch runs its segments (tables in LDS): 0 automatic, 2 never
     "step_one_fused": 46,      # step_render_delta on a batch of one with a completion word: 1 (default) one launch, 2 ... writing whole rows, 0 two launches
     "bind_min_envs": 36,       # pw_batch_bind: environments of a batch that must play a puzzle for it to be bound (0 = default 48)
     "bind_fused": 37,          # launches of a bound batch: 0 / "auto" one launch for segments + lane groups, 2 two launches

@@ -223,6 +223,7 @@ struct PwEngine {
   uint32_t* d_bind_mismatch;  // device counter (StepArgs::bind_mismatch)
   PwMailbox* mailbox;     // the open resident step kernel of this engine (pw_mailbox_open), or NULL
   int mailbox_mode;       // PW_OPT_MAILBOX_MODE
+  int mailbox_seg;        // PW_OPT_MAILBOX_SEG: 0 the segment form for bound batches (default), 2 never
   unsigned long long* step_signal;     // pw_engine_set_step_signal: completion word of pw_step_render_delta on a batch of one
   unsigned long long step_signal_seq;  // ... and the last number written to it
   uint32_t* d_dirty;       // per-environment dirty row record of pw_step_render_delta (grown on demand)

@@ -210,7 +210,8 @@ def test_idle_limit_ends_the_kernel():
     _same_state(a, b)
 
 
-@pytest.mark.parametrize("pool,B,tables", [("level1", 4096, True), ("level1", 1500, False), ("c4mix", 4096, True), ("level0_big", 3000, True)])
+@pytest.mark.parametrize("pool,B,tables", [("level1", 4096, True), ("level1", 1500, False), ("c4mix", 4096, True), ("level0_big", 3000, True),
+                                           ("heavy", 1024, True)])
 def test_any_set_through_lane_step(pool, B, tables):
     """Sets that do not fit 8 x 8 boards: the resident kernel steps them with lane_step (one lane per environment; overlap tables
     where the engine has them for every puzzle, row bitboards otherwise) -- N_pad 16 (Level 1), 32 (the C4 mix with `Clean Sweep`),
@@ -235,6 +236,12 @@ def test_any_set_through_lane_step(pool, B, tables):
                 plans[len(texts)] = _plan(f"level{lv}", p)
                 texts.append(open(p).read())
         texts.append(open([p for p in bd.level_paths(2) if "Clean Sweep" in p][0]).read())
+    elif pool == "heavy":  # 12 .. 19 movables: four and eight lanes per environment in the segment form
+        texts = []
+        for lv, name in ((2, "Clean Sweep"), (4, "Mind The Gap"), (3, "Yin Yang"), (3, "Rocky Shore")):
+            p = [q for q in bd.level_paths(lv) if name in q][0]
+            plans[len(texts)] = _plan(f"level{lv}", p)
+            texts.append(open(p).read())
     else:
         texts = [t for t in bd.level0_texts().values() if len(t.strip().splitlines()) + 2 > 8][:30]
         assert len(texts) == 30
@@ -252,6 +259,9 @@ def test_any_set_through_lane_step(pool, B, tables):
     torch.cuda.synchronize()
     solved = 0
     with a.mailbox() as mb:
+        # (round 6: a batch whose every environment sits in a segment of its binding is stepped by the segments -- Level 1 at 60
+        # environments per puzzle, the big Level-0 puzzles at 100; the others one lane per environment)
+        assert a.engine.get_option("mailbox_form") == (2 if (pool, B) in (("level1", 4096), ("level0_big", 3000), ("heavy", 1024)) and tables else 1)
         for t in range(T):
             r, te, tr = mb.step(acts[t] if t % 2 else acts_dev[t])
             _, r2, te2, tr2 = b.step(acts_dev[t])
@@ -323,7 +333,7 @@ def _oracle_actions(rng, ids, plans, T, every):
     return acts, driven
 
 
-def _mailbox_against_oracle(texts, plans, ids, T, max_steps, host_actions, ahead, seed):
+def _mailbox_against_oracle(texts, plans, ids, T, max_steps, host_actions, ahead, seed, seg=None):
     import torch
 
     from oracle import c_oracle
@@ -343,6 +353,8 @@ def _mailbox_against_oracle(texts, plans, ids, T, max_steps, host_actions, ahead
     acts_dev = torch.as_tensor(acts).to(vec.device)
     vec.reset()
     torch.cuda.synchronize()
+    if seg is not None:  # the form of the resident kernel: the segments of the bound batch (True) or one lane per environment (False)
+        vec.engine.set_option("mailbox_seg", 0 if seg else 2)
 
     def check_slot(t, slot):
         r, te, tr = slot
@@ -358,6 +370,8 @@ def _mailbox_against_oracle(texts, plans, ids, T, max_steps, host_actions, ahead
         assert (vec.terminated.cpu().numpy() == want_te[t]).all() and (vec.truncated.cpu().numpy() == want_tr[t]).all(), t
 
     with vec.mailbox(ring=max(8, ahead)) as mb:
+        if seg is not None:
+            assert vec.engine.get_option("mailbox_form") == (2 if seg else 1)
         if ahead <= 1:
             for t in range(T):
                 check_slot(t, mb.step(acts[t] if host_actions else acts_dev[t]))
@@ -395,8 +409,8 @@ def test_c2_mailbox_against_the_oracle(host_actions, ahead):
     _mailbox_against_oracle([text], {0: plan}, ids, 416, 25, host_actions, ahead, seed=11 + ahead)
 
 
-@pytest.mark.parametrize("host_actions,ahead", [(False, 1), (True, 8)])
-def test_level1_mailbox_against_the_oracle(host_actions, ahead):
+@pytest.mark.parametrize("host_actions,ahead,seg", [(False, 1, True), (True, 8, True), (False, 8, True), (False, 1, False), (True, 8, False)])
+def test_level1_mailbox_against_the_oracle(host_actions, ahead, seg):
     """4 096 environments over the 68 Level-1 puzzles (the resident kernel's one-lane-per-environment table formulation), a third of
     them on the human solution plans of data/solutions."""
     import bench
@@ -412,4 +426,4 @@ def test_level1_mailbox_against_the_oracle(host_actions, ahead):
                     plans[i] = np.array(["LRUD".index(c) for c in line.split(":", 1)[1].strip()], np.uint8)
     B = 4096
     ids = (np.arange(B, dtype=np.int64) * len(texts)) // B
-    _mailbox_against_oracle(texts, plans, ids, 400, 120, host_actions, ahead, seed=23 + ahead)
+    _mailbox_against_oracle(texts, plans, ids, 400, 120, host_actions, ahead, seed=23 + ahead, seg=seg)
