@@ -517,6 +517,8 @@ int pw_batch_unbind(PwEngine* e);
  *   - any set, batches of up to 65 536 environments (every workgroup is resident): sets whose puzzles all fit 8 x 8 cells with at
  *     most 8 movables (PW_OPT_STEP_BOARD_SET = 1: the Level-0 families of 5 x 5 puzzles) are stepped by the whole-grid boards pw_step
  *     launches for them, the others one lane per environment over their overlap tables / row bitboards (pw_step_lane_kernel's step);
+ *     a batch bound with pw_batch_bind whose every environment sits in a segment (and whose segments are all resident at once) is
+ *     stepped by the segments -- the puzzle's tables in LDS, copied once at the open (PW_OPT_MAILBOX_SEG / PW_OPT_MAILBOX_FORM);
  *   - puzzle_id is read once, at the open: episodes restart (PW_STEP_AUTORESET) on the same puzzle;
  *   - everything queued on other streams for the arrays must be complete before the open, and while the mailbox is open the
  *     engine's other stepping calls fail (the environments live in the resident kernel); pw_counters is current after the close
