@@ -578,7 +578,8 @@ int pw_step_render(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions
  * reset by PW_STEP_AUTORESET, which also covers a puzzle_id changed by pw_resample).  uint8 /
  * pixels_per_cell 3 engines; any other engine silently takes the pw_step_render path.
  * Returns PW_OK, or 1 / 2 when the launch will also write the engine's completion word (below) -- 2: the step and the redraw were ONE
- * launch (PW_OPT_STEP_ONE_FUSED) whose hand-over word carries a launch number: such a call must not be captured into a graph and replayed. */
+ * launch (PW_OPT_STEP_ONE_FUSED) whose hand-over words carry a launch number -- a call made while its stream is being captured takes the
+ * two launches (1): a graph may replay those. */
 int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* actions, int8_t* pos,
                          int32_t* steps, double* reward, int8_t* dgoals, uint8_t* terminated,
                          uint8_t* truncated, void* obs, int64_t env_stride_bytes, int32_t batch,
