@@ -181,7 +181,8 @@ def test_incremental_full_size_is_a_pure_function_of_the_state():
 
 @pytest.mark.parametrize("kw", [dict(observation="float32", pixels_per_cell=20, border_width=2),   # the gym default: 8 workgroups
                                 dict(observation="uint8", pixels_per_cell=8, border_width=2),      # a small frame: one workgroup
-                                dict(observation="float32", pixels_per_cell=5, border_width=1)])
+                                dict(observation="float32", pixels_per_cell=5, border_width=1),
+                                dict(observation="uint8", pixels_per_cell=20, border_width=3)])    # uint8 frames of >= 64 KB: the one-launch form in uint8
 @pytest.mark.parametrize("fused", [1, 2, 0])  # PW_OPT_STEP_ONE_FUSED: one launch writing the changed columns / whole rows, two launches
 def test_batch_of_one_completion_word_and_split_redraw(golden, kw, fused):
     """pw_step_render_delta on a batch of ONE (what the gym / dm_env adapters launch): the changed rows leave through eight
