@@ -339,6 +339,7 @@ int64_t pw_engine_obs_stride(const PwEngine* e);       /* recommended env stride
                                       per environment over the tables in memory).  Same results. */
 #define PW_OPT_MAILBOX_FORM 48       /* read-only: 0 no mailbox open, 1 its kernel steps one lane per environment (whole-grid boards / tables in memory), 2 the segments
                                       of the bound batch */
+#define PW_OPT_STEP_ONE_APPLIES 49    /* read-only: 1 when pw_step_render_delta on a batch of one with a completion word takes the one-launch form on this engine */
 #define PW_OPT_OBS_TUNE_MS 40        /* pw_obs_alloc_tuned: wall-clock budget of the candidate screen in milliseconds (0 = default 10 000): no
                                       further candidate is allocated once it is spent (the best so far is kept and tuned) -- bounds the
                                       constructor when several ranks of a node screen at the same time */
@@ -591,6 +592,13 @@ int pw_step_render_delta(PwEngine* e, const int32_t* puzzle_id, const uint8_t* a
  * returns 1 instead of PW_OK and the last workgroup of its last kernel writes k -- the number of such calls since this call -- into the word after
  * everything else it wrote: the host polls the word instead of synchronising the stream (~8 us of runtime per step here). */
 int pw_engine_set_step_signal(PwEngine* e, void* word);
+
+/* For the same callers: the state arrays of their batch of one may live in DEVICE memory (a kernel that reads and writes pinned host
+ * memory across the link lasts ~5 us whatever it computes) when the ONE-launch form of pw_step_render_delta applies
+ * (PW_OPT_STEP_ONE_APPLIES = 1: returns 2) -- that launch then also writes a copy of what the step left into `block`, 16 + 2 * NP bytes of
+ * pinned, device-addressable host memory (8-byte aligned; NULL switches it off), before the completion word:
+ *   [0] reward float64 | [8] steps int32 | [12] terminated | [13] truncated | [14] dgoals int8 | [16 ...] (x, y) int8 pairs. */
+int pw_engine_set_step_host_copy(PwEngine* e, void* block);
 
 /* Planner successor expansion, best_first_search.h:76-78 calling
  * PushWorldPuzzle::getNextState (pushworld_puzzle.cc:386-460) and satisfiesGoal (:462-469)

@@ -127,6 +127,7 @@ SIGNATURES = {
     "pw_mailbox_layout": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
     "pw_mailbox_close": (c_int, [c_void_p]),
     "pw_engine_set_step_signal": (c_int, [c_void_p, c_void_p]),
+    "pw_engine_set_step_host_copy": (c_int, [c_void_p, c_void_p]),
     "pw_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pw_step_render": (
         c_int,
@@ -215,6 +216,7 @@ OPTIONS = {
     "step_lane_batch": 21,     # state-only launches of >= this many environments: one lane per environment (0 default, "never")
     "obs_tune_ms": 40,         # pw_obs_alloc_tuned: wall-clock budget of the candidate screen (0 = default 10 000 ms)
     "obs_screen_ms": 41,       # read-only: what the last screen took
+    "step_one_applies": 49,    # read-only: step_render_delta on a batch of one with a completion word is ONE launch on this engine
     "mailbox_form": 48,        # read-only: 0 no mailbox open, 1 lanes / boards, 2 the segments of the bound batch
     "mailbox_seg": 47,         # the resident kernel of a fully bound batch runs its segments (tables in LDS): 0 automatic, 2 never
     "step_one_fused": 46,      # step_render_delta on a batch of one with a completion word: 1 (default) one launch, 2 ... writing whole rows, 0 two launches
@@ -831,6 +833,11 @@ class Engine:
         """``pw_engine_set_step_signal``: ``word`` = a pinned int64 / uint64 tensor of one element, or None."""
         check(lib.pw_engine_set_step_signal(self.handle, None if word is None else c_void_p(word.data_ptr())))
         self._step_signal_keep = word
+
+    def set_step_host_copy(self, block) -> None:
+        """``pw_engine_set_step_host_copy``: ``block`` = a pinned uint8 tensor of 16 + 2 * NP bytes, or None."""
+        check(lib.pw_engine_set_step_host_copy(self.handle, None if block is None else c_void_p(block.data_ptr())))
+        self._step_host_copy_keep = block
 
     def next_state(self, puzzle_index: int, xy_in, action: int, xy_out, info=None) -> None:
         """``pw_next_state``: host buffers in / out (bytes-like of 2 N int8 each), one launch, no copy command."""

@@ -74,13 +74,20 @@ class SingleEnvCore:
         dev_t = self._engine.device
         npad = self._engine.np
         self._raw = torch.zeros((16 + 2 * npad,), dtype=torch.uint8).pin_memory()
+        # Where the step is ONE launch (frames of at least 64 KiB: the gym default), the state itself lives in DEVICE memory and that launch
+        # writes a copy of what it left into self._raw (pw_engine_set_step_host_copy): a kernel that reads and writes pinned host
+        # memory across the link lasts ~5 us whatever it computes (profiles/r06_c1_trace.txt).  PUSHWORLD_AMD_DEVICE_STATE=0: as before.
+        self._device_state = (self._engine.get_option("step_one_applies") == 1
+                              and os.environ.get("PUSHWORLD_AMD_DEVICE_STATE", "1") != "0")
+        self._dev_raw = torch.zeros((16 + 2 * npad,), dtype=torch.uint8, device=dev_t) if self._device_state else None
+        src = self._dev_raw if self._device_state else self._raw
         self._buf = {
-            "reward": self._raw[0:8].view(torch.float64),
-            "steps": self._raw[8:12].view(torch.int32),
-            "terminated": self._raw[12:13],
-            "truncated": self._raw[13:14],
-            "dgoals": self._raw[14:15].view(torch.int8),
-            "pos": self._raw[16:].view(torch.int8).view(1, npad, 2),
+            "reward": src[0:8].view(torch.float64),
+            "steps": src[8:12].view(torch.int32),
+            "terminated": src[12:13],
+            "truncated": src[13:14],
+            "dgoals": src[14:15].view(torch.int8),
+            "pos": src[16:].view(torch.int8).view(1, npad, 2),
         }
         self._pid = torch.zeros((1,), dtype=torch.int32, device=dev_t)
         self._acts = torch.arange(4, dtype=torch.uint8, device=dev_t)  # action a = the 1-element view [a : a + 1]
@@ -102,6 +109,8 @@ class SingleEnvCore:
         self._signal_np = self._signal.numpy()
         self._signalled = 0
         self._engine.set_step_signal(self._signal)
+        if self._device_state:
+            self._engine.set_step_host_copy(self._raw)
         self._stream = torch.cuda.current_stream(dev_t)
         # One GRAPH launch per step: the step's two launches (step kernel, redraw of the changed rows + completion
         # word) are captured once per action -- the action is a byte of self._acts, i.e. part of the captured pointer; four graphs --
@@ -206,6 +215,11 @@ class SingleEnvCore:
             self._eager_steps += 1
             if rc == 2:
                 self._graphs = False  # step + redraw are ONE launch already (PW_OPT_STEP_ONE_FUSED): cheaper than a graph replay, and not replayable
+            elif self._device_state:
+                # (the one launch did not run -- its option was switched off behind this object's back: the state is on the device, fetch it)
+                self._raw.copy_(self._dev_raw)
+                torch.cuda.current_stream(self._engine.device).synchronize()
+                self._graphs = False
             if self._graphs is None and signalled and self._eager_steps >= 8:
                 self._capture_graphs()
         self._steps += 1

@@ -142,6 +142,7 @@ struct PwEngine {
   int step_kernel;         // PW_OPT_STEP_KERNEL: 0 lane group (default), 1 wavefront per env, 2 lane per env
   bool force_fused;        // PW_OPT_FUSED_STEP_RENDER: pw_step_render always uses the single fused launch
   unsigned long long step_one_seq;  // launches of pw_step_render_one_kernel so far (its hand-over word)
+  uint8_t* step_host_copy; // pw_engine_set_step_host_copy: pinned block that receives a copy of what a one-launch step left (or NULL)
   int step_one_fused;      // PW_OPT_STEP_ONE_FUSED: pw_step_render_delta on a batch of one with a completion word is ONE launch (2: whole rows)
   bool force_lds_render;   // PW_OPT_RENDER_KERNEL = 1: per-environment LDS kernel even where the page kernel applies
   int64_t page_slice_envs; // PW_OPT_PAGE_SLICE_ENVS: environments per page-kernel launch (0 = what 2^31 chunks allow)
